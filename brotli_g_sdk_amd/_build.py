@@ -1,0 +1,49 @@
+"""In-tree native builds.  Everything is compiled with explicit commands (no JIT cache) so the
+resulting .so files travel with the repo snapshot to the GPU box."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+
+ENC_SO = os.path.join(CSRC, "libbrotlig_enc.so")
+HIP_SO = os.path.join(CSRC, "libbrotlig_hip.so")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_encoder(force=False):
+    src = [os.path.join(CSRC, "brotlig_encoder.cpp"), os.path.join(CSRC, "brotlig_encoder.h")]
+    if force or _stale(ENC_SO, src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ENC_SO, src[0]], cwd=CSRC)
+    return ENC_SO
+
+
+def hip_sources():
+    names = ["brotlig_hip.hip", "brotlig_kernels.h", "wave_ops.h", "brotlig_format.h"]
+    return [os.path.join(CSRC, n) for n in names] + [os.path.join(ROOT, "include", "brotlig_amd.h")]
+
+
+def build_hip(force=False):
+    src = hip_sources()
+    if force or _stale(HIP_SO, src):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_SO, src[0]]
+        subprocess.check_call(cmd, cwd=CSRC)
+    return HIP_SO
+
+
+def build_all(force=False):
+    build_encoder(force)
+    build_hip(force)

@@ -1,0 +1,169 @@
+"""Seeded synthetic inputs for the BASELINE.json configs.
+
+Everything is generated from seeds on whichever box runs the test/benchmark; nothing is shipped.
+All generators return uint8 numpy arrays."""
+import numpy as np
+
+PAGE = 65536
+
+
+def random_bytes(n, seed=0):
+    """Config 1: uniform random bytes (encodes as stored pages)."""
+    return np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)
+
+
+def runs(n, seed=1):
+    """Config 2: zeros interleaved with byte runs (run length ~U[1,300], value ~U{0..3})."""
+    rng = np.random.default_rng(seed)
+    k = n // 100 + 16
+    lens = rng.integers(1, 301, k)
+    vals = rng.integers(0, 4, k).astype(np.uint8)
+    vals[::2] = 0                                   # zeros interleaved with runs
+    out = np.repeat(vals, lens)
+    while len(out) < n:
+        out = np.concatenate([out, out])
+    return out[:n].copy()
+
+
+_VOCAB_CACHE = {}
+
+
+def _vocab(seed):
+    if seed not in _VOCAB_CACHE:
+        rng = np.random.default_rng(1000 + seed)
+        letters = np.frombuffer(b"etaoinshrdlucmfwypvbgkqjxz", dtype=np.uint8)
+        p = np.arange(1, 27, dtype=np.float64) ** -0.9
+        p /= p.sum()
+        words = []
+        for _ in range(4096):
+            ln = int(rng.integers(2, 11))
+            words.append(bytes(rng.choice(letters, ln, p=p)))
+        _VOCAB_CACHE[seed] = words
+    return _VOCAB_CACHE[seed]
+
+
+def text(n, seed=0):
+    """Word soup: Zipf over a 4k-word vocabulary with punctuation and line breaks."""
+    rng = np.random.default_rng(seed)
+    words = _vocab(seed % 4)
+    ranks = np.minimum(rng.zipf(1.25, n // 4 + 64) - 1, len(words) - 1)
+    seps = rng.choice(np.frombuffer(b"     ,.\n;", dtype=np.uint8), len(ranks))
+    parts = []
+    total = 0
+    for r, s in zip(ranks, seps):
+        w = words[r]
+        parts.append(w)
+        parts.append(bytes([s]))
+        total += len(w) + 1
+        if total >= n:
+            break
+    return np.frombuffer(b"".join(parts), dtype=np.uint8)[:n].copy()
+
+
+def records(n, seed=0):
+    """Structured binary records: a repeating 16-64 byte template with mutated fields."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(n + 64, dtype=np.uint8)
+    pos = 0
+    while pos < n:
+        rec = int(rng.integers(16, 65))
+        count = int(rng.integers(64, 1024))
+        tmpl = rng.integers(0, 256, rec, dtype=np.uint8)
+        block = np.tile(tmpl, count).reshape(count, rec)
+        nf = int(rng.integers(1, 4))
+        for _ in range(nf):                          # mutated fields: counters / small noise
+            col = int(rng.integers(0, rec))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                block[:, col] = (np.arange(count) + int(rng.integers(0, 256))) & 0xFF
+            elif kind == 1:
+                block[:, col] = rng.integers(0, 8, count, dtype=np.uint8)
+            else:
+                block[:, col] = rng.integers(0, 256, count, dtype=np.uint8)
+        flat = block.reshape(-1)
+        take = min(len(flat), n + 64 - pos)
+        out[pos:pos + take] = flat[:take]
+        pos += take
+    return out[:n].copy()
+
+
+def samples16(n, seed=0):
+    """Smooth 16-bit samples (random walk with small steps), little endian."""
+    rng = np.random.default_rng(seed)
+    m = n // 2 + 1
+    steps = rng.integers(-6, 7, m)
+    steps[rng.random(m) < 0.7] = 0
+    walk = (np.cumsum(steps) + 20000).astype(np.int64) & 0xFFFF
+    return walk.astype("<u2").view(np.uint8)[:n].copy()
+
+
+def mixed_page(page_index, seed=0, n=PAGE):
+    """One 'Silesia-like' page: the class is chosen per page with the BASELINE.md mix
+    (40 % text, 25 % records, 20 % 16-bit samples, 10 % byte runs, 5 % random)."""
+    rng = np.random.default_rng((seed << 20) ^ (page_index * 2654435761 & 0xFFFFFFFF))
+    u = rng.random()
+    s = int(rng.integers(0, 1 << 30))
+    if u < 0.40:
+        return text(n, s)
+    if u < 0.65:
+        return records(n, s)
+    if u < 0.85:
+        return samples16(n, s)
+    if u < 0.95:
+        return runs(n, s)
+    return random_bytes(n, s)
+
+
+def mixed(n, seed=0):
+    pages = [mixed_page(i, seed, min(PAGE, n - i * PAGE)) for i in range((n + PAGE - 1) // PAGE)]
+    return np.concatenate(pages)
+
+
+def bc_texture(fmt, width_blocks, height_blocks, seed=0, num_mips=1, pitch_bytes=0, aligned=False):
+    """Block-compressed texture bytes (BC1..BC5 layout): smooth endpoint gradients plus noisy
+    index bits.  Returns (bytes, total_size) laid out mip after mip with the row pitch the
+    reference derives (inc/common/BrotligDataConditioner.h:195-217)."""
+    rng = np.random.default_rng(seed)
+    block_bytes = {1: 8, 2: 16, 3: 16, 4: 8, 5: 16}[fmt]
+    chunks = []
+    w, h = width_blocks, height_blocks
+    mw, mh = (w * 4) // 2, (h * 4) // 2
+    for mip in range(num_mips):
+        if mip > 0:
+            w, h = (mw + 3) // 4, (mh + 3) // 4
+            mw //= 2
+            mh //= 2
+        pitch = w * block_bytes
+        if mip == 0 and pitch_bytes:
+            pitch = pitch_bytes
+        elif aligned:
+            pitch = (pitch + 255) // 256 * 256
+        tex = np.zeros((h, pitch), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        blocks = np.zeros((h, w, block_bytes), dtype=np.uint8)
+        g = ((xx * 3 + yy * 5) // 4 + int(rng.integers(0, 64)))
+        if fmt in (1, 2, 3):
+            col_off = block_bytes - 8
+            c0 = (g & 0x1F) | (((g // 2) & 0x3F) << 5) | (((g // 3) & 0x1F) << 11)
+            c1 = ((g + 1) & 0x1F) | ((((g // 2) + 1) & 0x3F) << 5) | ((((g // 3)) & 0x1F) << 11)
+            blocks[..., col_off + 0] = c0 & 0xFF
+            blocks[..., col_off + 1] = (c0 >> 8) & 0xFF
+            blocks[..., col_off + 2] = c1 & 0xFF
+            blocks[..., col_off + 3] = (c1 >> 8) & 0xFF
+            blocks[..., col_off + 4:col_off + 8] = rng.integers(0, 256, (h, w, 4), dtype=np.uint8) & \
+                rng.choice(np.array([0x00, 0x55, 0xFF, 0x0F], dtype=np.uint8), (h, w, 1))
+            if fmt == 2:
+                blocks[..., 0:8] = rng.integers(0, 16, (h, w, 8), dtype=np.uint8) * 17
+            if fmt == 3:
+                blocks[..., 0] = (g + 40) & 0xFF
+                blocks[..., 1] = (g + 8) & 0xFF
+                blocks[..., 2:8] = rng.integers(0, 256, (h, w, 6), dtype=np.uint8) & 0x3F
+        else:
+            for base in range(0, block_bytes, 8):
+                blocks[..., base + 0] = (g + 30 + base) & 0xFF
+                blocks[..., base + 1] = (g + base) & 0xFF
+                blocks[..., base + 2:base + 8] = rng.integers(0, 256, (h, w, 6), dtype=np.uint8) & 0x77
+        tex[:, :w * block_bytes] = blocks.reshape(h, w * block_bytes)
+        chunks.append(tex.reshape(-1))
+    data = np.concatenate(chunks)
+    return data
