@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the Brotli-G decode hot path on MI355X.
+
+One "step" = one pass of the decode path (prepare + page-decode kernels) over the whole batch of
+streams, inputs already resident in HBM.  Default workload = BASELINE.json configs[2], the one the
+metric is quoted on: 4 GiB of 64 KiB pages, Silesia-like mixed-entropy synthetic, as 16 streams x
+4096 pages (a stream holds at most 65535 pages, inc/DataStream.h:32).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+For N > 1 every rank decodes its own 16 streams (independent pages -> static shard, no data-path
+collective; weak scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PAGE = 65536
+
+
+def build_streams(kind, indices, pages_per_stream, distinct):
+    """Builds the streams with the given global indices (the seed of a stream is its index).
+    Returns (streams, expected_distinct) where expected_distinct[k] is the decompressed bytes of
+    the `distinct` pages stream k is tiled from."""
+    from brotli_g_sdk_amd import datagen as D, encoder as E
+    streams, expected = [], []
+    for seed in indices:
+        if kind == "mixed":
+            data = D.mixed(distinct * PAGE, seed)
+        elif kind == "runs":
+            data = D.runs(distinct * PAGE, seed + 1)
+        elif kind == "text":
+            data = D.text(distinct * PAGE, seed)
+        else:
+            raise SystemExit(f"unknown workload {kind}")
+        small = E.encode(data)
+        rep = pages_per_stream // distinct
+        streams.append(D.tile_stream(small, rep) if rep > 1 else small)
+        expected.append(data)
+    return streams, expected
+
+
+def cpu_baseline(streams, budget_s=12.0):
+    """Times the oracle (CPU restatement of DecodeCPU, reference thread policy) on as many of the
+    bench streams as fit in the budget.  The oracle is used here only as the reported baseline."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libbrotlig_oracle.so"))
+    lib.DecompressedSize.restype = ctypes.c_uint32
+    lib.DecompressedSize.argtypes = [ctypes.c_void_p]
+    lib.brotlig_oracle_decode.restype = ctypes.c_int
+    lib.brotlig_oracle_decode.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
+                                          ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    n0 = lib.DecompressedSize(streams[0].ctypes.data)
+    out = np.zeros(n0 + 64, dtype=np.uint8)
+    # untimed warm pass: page in the output buffer and the per-thread tables
+    osz, used = ctypes.c_uint32(n0), ctypes.c_int(0)
+    lib.brotlig_oracle_decode(len(streams[0]), streams[0].ctypes.data, ctypes.byref(osz), out.ctypes.data, 0, ctypes.byref(used))
+    total, t0, done = 0, time.perf_counter(), 0
+    outs = []
+    for s in streams:
+        n = lib.DecompressedSize(s.ctypes.data)
+        if n > n0:
+            break
+        osz = ctypes.c_uint32(n)
+        rc = lib.brotlig_oracle_decode(len(s), s.ctypes.data, ctypes.byref(osz), out.ctypes.data, 0, ctypes.byref(used))
+        if rc != 0:
+            raise SystemExit(f"oracle failed with {rc}")
+        total += osz.value
+        done += 1
+        if done == 1:
+            outs.append(out[:osz.value].copy())
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(total / dt / 1e9, 4), "unit": "GB/s", "cores": int(used.value), "kind": "port",
+            "sample": f"{done} of the bench streams ({total / 2**20:.0f} MiB decompressed), oracle/brotlig_oracle.c, "
+                      f"reference worker policy, host has {os.cpu_count()} logical CPUs"}, outs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="mixed", choices=["mixed", "runs", "text"])
+    ap.add_argument("--streams", type=int, default=16)
+    ap.add_argument("--pages-per-stream", type=int, default=4096)
+    ap.add_argument("--distinct", type=int, default=256, help="distinct encoded pages per stream (tiled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU decode path in the product)")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    from brotli_g_sdk_amd import api
+
+    api.DeviceSelfTest()
+    distinct = min(args.distinct, args.pages_per_stream)
+    from brotli_g_sdk_amd import shard
+    mine = shard.stream_indices(args.streams * world, world, rank)     # static contiguous shard of the stream list
+    streams, expected = build_streams(args.workload, mine, args.pages_per_stream, distinct)
+    dec = api.BatchDecoder(streams, device=dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dec.decode(check=False)
+    barrier()
+    t0 = time.perf_counter()
+    total_ms, kernel_ms = dec.timed(0, args.steps)
+    barrier()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    wall_ms = shard.max_over_ranks(wall_ms)
+    kernel_ms_max = shard.max_over_ranks(kernel_ms)
+
+    # bit-exactness: every page of every stream against the bytes it was encoded from
+    dec.poison_output()
+    dec.decode(check=True)
+    torch.cuda.synchronize()
+    ok = True
+    for k in range(len(streams)):
+        exp = torch.from_numpy(expected[k]).to(dev)
+        got = dec.d_out[dec.out_offs[k]:dec.out_offs[k] + dec.sizes[k]].view(-1, exp.numel())
+        ok = ok and bool((got == exp.unsqueeze(0)).all())
+    if world > 1:
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+
+    per_rank_u = dec.decompressed_bytes
+    per_rank_c = dec.compressed_bytes
+    ms_per_step = wall_ms / args.steps
+    total_u = shard.sum_over_ranks(per_rank_u)
+    value = total_u / (ms_per_step * 1e-3) / 1e9
+    achieved = (per_rank_u + per_rank_c) / (kernel_ms * 1e-3) / 1e9
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, outs = cpu_baseline(streams)
+        gpu0 = dec.output(0)
+        if not np.array_equal(outs[0], gpu0):
+            ok = False
+
+    if rank == 0:
+        line = {
+            "metric": "decompressed GB/s, Brotli-G decode, bit-exact vs DecodeCPU",
+            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "bit_exact": ok,
+            "config": {"workload": f"{args.streams} streams x {args.pages_per_stream} pages x 64 KiB per GPU "
+                                   f"({per_rank_u / 2**30:.2f} GiB), '{args.workload}' synthetic "
+                                   f"(BASELINE.json configs[2] when mixed), {distinct} distinct encoded pages per stream "
+                                   f"tiled, compression ratio {per_rank_u / per_rank_c:.2f}",
+                       "sharding": "independent streams per GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "kernel": "brotlig_decode_kernel", "kernel_ms": round(kernel_ms_max, 4),
+                         "algorithmic_bytes_per_launch": per_rank_u + per_rank_c},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench: GPU output is not bit-exact")
+
+
+if __name__ == "__main__":
+    main()

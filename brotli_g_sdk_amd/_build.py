@@ -31,7 +31,7 @@ def build_encoder(force=False):
 
 
 def hip_sources():
-    names = ["brotlig_hip.hip", "brotlig_kernels.h", "wave_ops.h", "brotlig_format.h"]
+    names = ["brotlig_hip.hip", "brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h"]
     return [os.path.join(CSRC, n) for n in names] + [os.path.join(ROOT, "include", "brotlig_amd.h")]
 
 

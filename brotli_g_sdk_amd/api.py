@@ -1,0 +1,168 @@
+"""Host-side mirror of the reference's decode interface, over the C ABI in include/brotlig_amd.h.
+
+Same names and argument meaning as the reference (`DecompressedSize`, inc/BrotligDecoder.h:32;
+`DecodeGPU`, sample/BrotligGPUDecoder.h:24), plus `BatchDecoder` for the device-pointer batch
+entry the benchmark times.  There is no CPU decode path here: if libbrotlig_hip.so is missing or
+no HIP device is usable, the calls raise.  torch is used only to own device memory and streams.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _build
+
+BROTLIG_OK = 0
+BROTLIG_ERROR_CORRUPT_STREAM = 14
+BROTLIG_ERROR_INCORRECT_STREAM_FORMAT = 15
+BROTLIG_ERROR_GENERIC = 16
+
+
+class BrotligError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"{what} failed with BROTLIG_ERROR {code}")
+        self.code = code
+
+
+class _StreamDesc(ctypes.Structure):
+    _fields_ = [("in_offset", ctypes.c_uint64), ("out_offset", ctypes.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libbrotlig_hip.so (building it in-tree with hipcc if needed).  Raises if absent."""
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(_build.build_hip())
+        L.DecompressedSize.restype = ctypes.c_uint32
+        L.DecompressedSize.argtypes = [ctypes.c_void_p]
+        L.DecodeGPU.restype = ctypes.c_int
+        L.DecodeGPU.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
+                                ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
+        L.BrotligDecodeWorkspaceSize.restype = ctypes.c_size_t
+        L.BrotligDecodeWorkspaceSize.argtypes = [ctypes.c_uint32]
+        batch = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32,
+                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        L.BrotligDecodeBatchDevice.restype = ctypes.c_int
+        L.BrotligDecodeBatchDevice.argtypes = batch
+        L.BrotligDecodeBatchStatus.restype = ctypes.c_int
+        L.BrotligDecodeBatchStatus.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.BrotligDecodeBatchTimed.restype = ctypes.c_int
+        L.BrotligDecodeBatchTimed.argtypes = batch + [ctypes.c_uint32, ctypes.c_uint32,
+                                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.BrotligDeviceSelfTest.restype = ctypes.c_int
+        L.BrotligKernelLdsBytes.restype = ctypes.c_uint32
+        L.BrotligKernelGridSize.restype = ctypes.c_uint32
+        _lib = L
+    return _lib
+
+
+def DecompressedSize(src) -> int:
+    """uint32_t DecompressedSize(uint8_t* src) -- inc/BrotligDecoder.h:32."""
+    a = np.ascontiguousarray(np.frombuffer(src, dtype=np.uint8) if not isinstance(src, np.ndarray) else src, dtype=np.uint8)
+    return int(lib().DecompressedSize(a.ctypes.data))
+
+
+def DecodeGPU(src, output_size=None):
+    """BROTLIG_ERROR DecodeGPU(useWarpDevice, input_size, input, output_size, output, time)
+    -- sample/BrotligGPUDecoder.h:24.  Host bytes in, host bytes out.
+    Returns (output ndarray, kernel_time_ms)."""
+    a = np.ascontiguousarray(np.frombuffer(src, dtype=np.uint8) if not isinstance(src, np.ndarray) else src, dtype=np.uint8)
+    cap = DecompressedSize(a) if output_size is None else int(output_size)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    osz = ctypes.c_uint32(cap)
+    t = ctypes.c_double(0.0)
+    rc = lib().DecodeGPU(0, len(a), a.ctypes.data, ctypes.byref(osz), out.ctypes.data, ctypes.byref(t))
+    if rc != BROTLIG_OK:
+        raise BrotligError(rc, "DecodeGPU")
+    return out[:osz.value], t.value
+
+
+def DeviceSelfTest():
+    rc = lib().BrotligDeviceSelfTest()
+    if rc != BROTLIG_OK:
+        raise BrotligError(rc, "BrotligDeviceSelfTest")
+
+
+class BatchDecoder:
+    """Owns the device buffers for a batch of streams and decodes them with one enqueue
+    (BrotligDecodeBatchDevice).  `streams` is a list of uint8 arrays, each one .brotlig stream."""
+
+    def __init__(self, streams, device="cuda:0", out_sizes=None):
+        import torch
+        self.torch = torch
+        self.device = torch.device(device)
+        L = lib()
+        n = len(streams)
+        sizes = [int(DecompressedSize(s)) for s in streams] if out_sizes is None else [int(x) for x in out_sizes]
+        in_offs, pos = [], 0
+        for s in streams:
+            in_offs.append(pos)
+            pos += (len(s) + 15) // 16 * 16
+        self.in_bytes = pos
+        out_offs, opos = [], 0
+        precon = False
+        for s, sz in zip(streams, sizes):
+            out_offs.append(opos)
+            page = 32768 << (int(s[4]) & 3)
+            precon = precon or bool((int(s[6]) >> 4) & 1)
+            opos += (sz + page - 1) // page * page
+        self.out_bytes = opos
+        self.sizes, self.out_offs, self.n = sizes, out_offs, n
+        self.compressed_bytes = int(sum(len(s) for s in streams))
+        self.decompressed_bytes = int(sum(sizes))
+        host_in = np.zeros(pos + 64, dtype=np.uint8)
+        for o, s in zip(in_offs, streams):
+            host_in[o:o + len(s)] = s
+        desc = np.zeros((n, 2), dtype=np.uint64)
+        desc[:, 0] = in_offs
+        desc[:, 1] = out_offs
+        self.d_in = torch.from_numpy(host_in).to(self.device)
+        self.d_desc = torch.from_numpy(desc.view(np.int64)).to(self.device)
+        self.d_out = torch.empty(opos + 64, dtype=torch.uint8, device=self.device)
+        self.d_scratch = torch.empty(opos + 64, dtype=torch.uint8, device=self.device) if precon else None
+        self.ws_bytes = int(L.BrotligDecodeWorkspaceSize(n))
+        self.d_ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+
+    def _args(self, stream):
+        scratch = self.d_scratch.data_ptr() if self.d_scratch is not None else None
+        return [self.d_in.data_ptr(), self.in_bytes, self.d_out.data_ptr(), self.out_bytes, self.d_desc.data_ptr(),
+                self.n, self.d_ws.data_ptr(), self.ws_bytes, scratch, stream]
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def decode(self, check=True):
+        """Enqueue one decode of the whole batch on torch's current stream."""
+        with self.torch.cuda.device(self.device):
+            st = self._stream()
+            rc = lib().BrotligDecodeBatchDevice(*self._args(st))
+            if rc != BROTLIG_OK:
+                raise BrotligError(rc, "BrotligDecodeBatchDevice")
+            if check:
+                rc = lib().BrotligDecodeBatchStatus(self.d_ws.data_ptr(), st)
+                if rc != BROTLIG_OK:
+                    raise BrotligError(rc, "BrotligDecodeBatchStatus")
+
+    def timed(self, warmup, steps):
+        """Returns (total_ms over `steps` passes, average decode-kernel ms), both from HIP events on
+        the launch stream."""
+        with self.torch.cuda.device(self.device):
+            st = self._stream()
+            total, kern = ctypes.c_double(0.0), ctypes.c_double(0.0)
+            rc = lib().BrotligDecodeBatchTimed(*self._args(st), warmup, steps, ctypes.byref(total), ctypes.byref(kern))
+            if rc != BROTLIG_OK:
+                raise BrotligError(rc, "BrotligDecodeBatchTimed")
+            rc = lib().BrotligDecodeBatchStatus(self.d_ws.data_ptr(), st)
+            if rc != BROTLIG_OK:
+                raise BrotligError(rc, "BrotligDecodeBatchStatus")
+            return total.value, kern.value
+
+    def output(self, i):
+        """Decompressed bytes of stream i as a host uint8 array."""
+        o = self.out_offs[i]
+        return self.d_out[o:o + self.sizes[i]].cpu().numpy()
+
+    def poison_output(self, value=0xCD):
+        self.d_out.fill_(value)

@@ -1,0 +1,218 @@
+// brotlig_hip.hip -- C ABI (include/brotlig_amd.h) over the gfx950 decode kernels.
+//
+// Host side of the drop-in boundary: replaces sample/BrotligGPUDecoder.cpp:260-748 (D3D12 device,
+// queue, PSO, upload/readback heaps, timestamp queries) with HIP runtime calls, and exposes the
+// shader's buffer-level contract (input / meta / output, BrotliGCompute.hlsl:93-95) as a
+// device-pointer batch call.  No decoding happens on the host.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "brotlig_amd.h"
+#include "brotlig_kernels.h"
+
+using namespace brotlig;
+
+namespace {
+
+static_assert(sizeof(BrotligStreamDesc) == sizeof(StreamDesc), "descriptor layout");
+
+#define HIP_OK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { \
+    fprintf(stderr, "brotlig_hip: %s failed: %s\n", #expr, hipGetErrorString(_e)); return BROTLIG_ERROR_GENERIC; } } while (0)
+
+// Device workspace (the reference's `meta` buffer): word 0 status, word 1 page counter, word 2
+// preconditioned-stream count, words 4.. page_base[num_streams + 1], then (1 KiB aligned) one
+// DcTable per stream.
+constexpr size_t kWsHeaderWords = 4;
+size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 1023u) & ~(size_t)1023u; }
+size_t workspace_bytes(uint32_t n) { return dc_offset(n) + (size_t)n * sizeof(DcTable); }
+
+int g_grid = 0;
+int g_decond_grid = 1024;
+
+BROTLIG_ERROR grid_size(int* out)
+{
+    if (g_grid == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        HIP_OK(hipGetDevice(&dev));
+        HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, brotlig_decode_kernel, 64, 0));
+        if (per_cu < 1) per_cu = 1;
+        g_grid = cus * per_cu;
+        g_decond_grid = cus * 8;
+    }
+    *out = g_grid;
+    return BROTLIG_OK;
+}
+
+DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
+                     const BrotligStreamDesc* d_streams, uint32_t n, void* d_ws, void* d_scratch)
+{
+    uint32_t* ws = static_cast<uint32_t*>(d_ws);
+    DecodeArgs a{};
+    a.in = static_cast<const uint8_t*>(d_in); a.in_bytes = in_bytes;
+    a.out = static_cast<uint8_t*>(d_out); a.out_bytes = out_bytes;
+    a.scratch = static_cast<uint8_t*>(d_scratch);
+    a.streams = reinterpret_cast<const StreamDesc*>(d_streams); a.num_streams = n;
+    a.status = ws; a.work_counter = ws + 1; a.page_base = ws + kWsHeaderWords;
+    a.dc = reinterpret_cast<DcTable*>(static_cast<uint8_t*>(d_ws) + dc_offset(n));
+    return a;
+}
+
+// prepare (page counts -> prefix) then the persistent page-decode kernel; k0/k1 bracket the latter
+BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
+{
+    int grid = 0;
+    if (BROTLIG_ERROR e = grid_size(&grid)) return e;
+    HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(1), dim3(64), 0, s, a);
+    if (k0) HIP_OK(hipEventRecord(k0, s));
+    hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
+    if (k1) HIP_OK(hipEventRecord(k1, s));
+    hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(g_decond_grid), dim3(256), 0, s, a);
+    HIP_OK(hipGetLastError());
+    return BROTLIG_OK;
+}
+
+BROTLIG_ERROR status_to_error(uint32_t st)
+{
+    if (st & kStatusBadHeader) return BROTLIG_ERROR_CORRUPT_STREAM;
+    if (st & kStatusBadPage) return BROTLIG_ERROR_GENERIC;
+    return BROTLIG_OK;
+}
+
+struct DevBuf {             // hipFree on scope exit
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" uint32_t DecompressedSize(uint8_t* src)
+{
+    uint32_t w0, w1;
+    memcpy(&w0, src, 4); memcpy(&w1, src + 4, 4);
+    StreamInfo si;
+    parse_stream_header(w0, w1, si);
+    return uncompressed_size(si);
+}
+
+extern "C" size_t BrotligDecodeWorkspaceSize(uint32_t num_streams) { return workspace_bytes(num_streams); }
+
+extern "C" BROTLIG_ERROR BrotligDecodeBatchDevice(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
+                                                  const BrotligStreamDesc* d_streams, uint32_t num_streams,
+                                                  void* d_workspace, size_t ws_bytes, void* d_scratch, void* hip_stream)
+{
+    if (!d_in || !d_out || !d_streams || !d_workspace || num_streams == 0) return BROTLIG_ERROR_GENERIC;
+    if (ws_bytes < workspace_bytes(num_streams)) return BROTLIG_ERROR_GENERIC;
+    const DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, d_scratch);
+    return enqueue(a, static_cast<hipStream_t>(hip_stream), nullptr, nullptr);
+}
+
+extern "C" BROTLIG_ERROR BrotligDecodeBatchStatus(const void* d_workspace, void* hip_stream)
+{
+    if (!d_workspace) return BROTLIG_ERROR_GENERIC;
+    uint32_t st = 0;
+    HIP_OK(hipMemcpyAsync(&st, d_workspace, sizeof st, hipMemcpyDeviceToHost, static_cast<hipStream_t>(hip_stream)));
+    HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
+    return status_to_error(st);
+}
+
+extern "C" BROTLIG_ERROR BrotligDecodeBatchTimed(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
+                                                 const BrotligStreamDesc* d_streams, uint32_t num_streams,
+                                                 void* d_workspace, size_t ws_bytes, void* d_scratch, void* hip_stream,
+                                                 uint32_t warmup, uint32_t steps, double* total_ms, double* decode_kernel_ms)
+{
+    if (!d_in || !d_out || !d_streams || !d_workspace || num_streams == 0 || steps == 0) return BROTLIG_ERROR_GENERIC;
+    if (ws_bytes < workspace_bytes(num_streams)) return BROTLIG_ERROR_GENERIC;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, d_scratch);
+    for (uint32_t i = 0; i < warmup; ++i) if (BROTLIG_ERROR e = enqueue(a, s, nullptr, nullptr)) return e;
+    std::vector<hipEvent_t> ev(2 * (size_t)steps + 2);
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipEventRecord(ev[2 * steps], s));
+    for (uint32_t i = 0; i < steps; ++i) if (BROTLIG_ERROR e = enqueue(a, s, ev[2 * i], ev[2 * i + 1])) return e;
+    HIP_OK(hipEventRecord(ev[2 * steps + 1], s));
+    HIP_OK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, ev[2 * steps], ev[2 * steps + 1]));
+    if (total_ms) *total_ms = ms;
+    double ksum = 0.0;
+    for (uint32_t i = 0; i < steps; ++i) { HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); ksum += ms; }
+    if (decode_kernel_ms) *decode_kernel_ms = ksum / steps;
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return BROTLIG_OK;
+}
+
+extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, const uint8_t* input,
+                                   uint32_t* output_size, uint8_t* output, double* time_ms)
+{
+    if (!input || !output || !output_size || input_size < 8) return BROTLIG_ERROR_CORRUPT_STREAM;
+    uint32_t w0, w1;
+    memcpy(&w0, input, 4); memcpy(&w1, input + 4, 4);
+    StreamInfo si;
+    // src/BrotligDecoder.cpp:437-446: magic first, then id
+    if ((w0 & 0xFF) != (((w0 >> 8) & 0xFF) ^ 0xFF)) return BROTLIG_ERROR_CORRUPT_STREAM;
+    if (!parse_stream_header(w0, w1, si)) return BROTLIG_ERROR_INCORRECT_STREAM_FORMAT;
+    const uint32_t out_size = uncompressed_size(si);
+    if (*output_size < out_size) return BROTLIG_ERROR_GENERIC;
+    if ((uint64_t)si.header_bytes + 4ull * si.num_pages > input_size) return BROTLIG_ERROR_CORRUPT_STREAM;
+
+    const uint64_t in_alloc = ((uint64_t)input_size + 15u) & ~15ull;
+    const uint64_t out_alloc = (((uint64_t)si.num_pages * si.page_size) + 15u) & ~15ull;
+    DevBuf d_in, d_out, d_scratch, d_ws, d_desc;
+    HIP_OK(hipMalloc(&d_in.p, in_alloc + 64));
+    HIP_OK(hipMalloc(&d_out.p, out_alloc));
+    if (si.preconditioned) HIP_OK(hipMalloc(&d_scratch.p, out_alloc));
+    HIP_OK(hipMalloc(&d_ws.p, workspace_bytes(1)));
+    HIP_OK(hipMalloc(&d_desc.p, sizeof(BrotligStreamDesc)));
+    const BrotligStreamDesc desc{0, 0};
+    HIP_OK(hipMemset(static_cast<uint8_t*>(d_in.p) + (in_alloc + 64 - 80), 0, 80));
+    HIP_OK(hipMemcpy(d_in.p, input, input_size, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_desc.p, &desc, sizeof desc, hipMemcpyHostToDevice));
+
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    const DecodeArgs a = make_args(d_in.p, input_size, d_out.p, out_alloc, static_cast<BrotligStreamDesc*>(d_desc.p), 1,
+                                   d_ws.p, d_scratch.p);
+    BROTLIG_ERROR err = enqueue(a, nullptr, e0, e1);
+    if (err == BROTLIG_OK) err = BrotligDecodeBatchStatus(d_ws.p, nullptr);
+    float ms = 0.f;
+    if (err == BROTLIG_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != BROTLIG_OK) return err;
+    HIP_OK(hipMemcpy(output, d_out.p, out_size, hipMemcpyDeviceToHost));
+    *output_size = out_size;                                            // src/BrotligDecoder.cpp:490
+    if (time_ms) *time_ms = ms;
+    return BROTLIG_OK;
+}
+
+extern "C" BROTLIG_ERROR BrotligDeviceSelfTest(void)
+{
+    DevBuf d;
+    HIP_OK(hipMalloc(&d.p, 384 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(brotlig_selftest_kernel, dim3(1), dim3(64), 0, nullptr, static_cast<uint32_t*>(d.p));
+    uint32_t h[384];
+    HIP_OK(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
+    const uint32_t* v = h + 320;
+    for (uint32_t lane = 0; lane < 64; ++lane) {
+        const uint32_t base = lane & 32u;
+        uint32_t sum = 0, mx = 0, bal = 0;
+        for (uint32_t l = base; l < base + 32; ++l) {
+            if (l <= lane) sum += v[l];
+            mx = v[l] > mx ? v[l] : mx;
+            if (v[l] & 1u) bal |= 1u << (l - base);
+        }
+        if (h[lane] != sum || h[64 + lane] != sum || h[128 + lane] != bal ||
+            h[192 + lane] != v[base | ((lane * 7u + 3u) & 31u)] || h[256 + lane] != mx) {
+            fprintf(stderr, "brotlig_hip: wave primitive self-test failed at lane %u\n", lane);
+            return BROTLIG_ERROR_GENERIC;
+        }
+    }
+    return BROTLIG_OK;
+}
+
+extern "C" uint32_t BrotligKernelLdsBytes(void) { return (uint32_t)sizeof(WaveLds); }
+extern "C" uint32_t BrotligKernelGridSize(void) { int g = 0; return grid_size(&g) == BROTLIG_OK ? (uint32_t)g : 0u; }

@@ -1,0 +1,810 @@
+// brotlig_kernels.h -- Brotli-G page decode for gfx950 (CDNA4), written from the format
+//  rather than from the reference shader.
+//
+// What it replaces: the reference's single D3D12 compute kernel CSMain
+// (src/decoder/BrotliGCompute.hlsl:1753-1882) and its CPU twin PageDecoder::Run
+// (src/decoder/PageDecoder.cpp:65-268).  Differences in design:
+//   * wave64 hosts TWO pages, one per 32-lane half (the format fixes 32 sub-streams per page);
+//   * symbols are decoded through LSB-first primary LUTs in LDS (one ds_read per symbol) with a
+//     canonical-code fallback for long codes, instead of the shader's <=16-step length search
+//     (BrotliGCompute.hlsl:500-526) or the CPU's three 64 KiB tables (BrotligHuffmanTable.cpp:44-71);
+//   * each lane streams its own sub-bitstream from global memory through a 64-bit window with a
+//     one-dword prefetch register;
+//   * literals are routed straight to their output position (no literal FIFO);
+//   * the LZ77 copies of a round run lane-per-command in dependency levels: every copy whose
+//     source lies below the first unfinished command is independent and executes at once
+//     (the shader walks the 32 commands serially, BrotliGCompute.hlsl:1401-1419);
+//   * work is pulled from one device-side page counter by persistent waves.
+//
+// Style rule: every wave::* call sits in wave-uniform control flow.  Per-lane loops and
+// branches contain only memory and ALU work.  (tests/sim runs this same source on the CPU with
+// one fiber per lane and checks the rule.)
+#pragma once
+#include <brotlig_wave_ops.h>
+
+#include "brotlig_format.h"
+
+namespace brotlig {
+
+// ---- kernel ABI -------------------------------------------------------------------------
+struct StreamDesc {
+    uint64_t in_offset;     // byte offset of the stream (its StreamHeader) in the input buffer
+    uint64_t out_offset;    // byte offset of its decompressed bytes in the output buffer
+};
+
+enum : uint32_t {           // bits of DecodeArgs::status[0]
+    kStatusBadHeader = 1u,  // magic / id check failed (src/BrotligDecoder.cpp:437-446)
+    kStatusBadPage = 2u,    // a page failed a bounds check (the reference has none: undefined there)
+};
+
+// Per-stream pre-conditioning parameters, derived once per launch by the prepare kernel from the
+// 8-byte PreconditionHeader (inc/DataStream.h:89-98) the way
+// BrotligDataconditionParams::Initialize does (inc/common/BrotligDataConditioner.h:92-237).
+struct DcTable {
+    uint32_t precon, swizzle, block_bytes, num_sub, num_mips, total_blocks, tex_bytes, color_mask;
+    uint32_t sub_size[kMaxSubBlocks], sub_off[kMaxSubBlocks], sub_stream_off[kMaxSubBlocks + 1];
+    uint32_t w[kMaxMips], h[kMaxMips], pitch[kMaxMips];
+    uint32_t mip_off_bytes[kMaxMips + 1], mip_off_blocks[kMaxMips + 1];
+    uint32_t item_prefix[kMaxMips + 1];     // de-conditioning work items (row chunks) before each mip
+    uint32_t pad[34];
+};
+static_assert(sizeof(DcTable) == 1024, "DcTable is addressed as 1 KiB records");
+
+struct DecodeArgs {
+    const uint8_t* in;  uint64_t in_bytes;
+    uint8_t* out;       uint64_t out_bytes;
+    uint8_t* scratch;   // conditioned-space staging for preconditioned streams (same layout as out)
+    const StreamDesc* streams; uint32_t num_streams;
+    uint32_t* page_base;    // [num_streams + 1] exclusive prefix of page counts
+    uint32_t* work_counter; // [1] next global page index
+    uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams
+    DcTable*  dc;           // [num_streams]
+};
+
+// ---- tunables ---------------------------------------------------------------------------
+constexpr int kLutBitsIcp = 10;
+constexpr int kLutBitsDist = 9;
+constexpr int kLutBitsLit = 10;
+constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index
+constexpr uint32_t kShortCopy = 32;         // copies up to this length run one-lane-per-command
+
+// insert / copy length codes: base | extra_bits << 16   (RFC 7932 section 5; the reference carries
+// them as sBrotligCmdLut, inc/common/BrotligCommandLut.h:41-747, and the shader regenerates them
+// by prefix sums, BrotliGCompute.hlsl:1061-1075)
+__device__ static const uint32_t kLenCodeTab[48] = {
+    // insert
+    0u | 0u << 16, 1u | 0u << 16, 2u | 0u << 16, 3u | 0u << 16, 4u | 0u << 16, 5u | 0u << 16,
+    6u | 1u << 16, 8u | 1u << 16, 10u | 2u << 16, 14u | 2u << 16, 18u | 3u << 16, 26u | 3u << 16,
+    34u | 4u << 16, 50u | 4u << 16, 66u | 5u << 16, 98u | 5u << 16, 130u | 6u << 16, 194u | 7u << 16,
+    322u | 8u << 16, 578u | 9u << 16, 1090u | 10u << 16, 2114u | 12u << 16, 6210u | 14u << 16, 22594u | 24u << 16,
+    // copy
+    2u | 0u << 16, 3u | 0u << 16, 4u | 0u << 16, 5u | 0u << 16, 6u | 0u << 16, 7u | 0u << 16,
+    8u | 0u << 16, 9u | 0u << 16, 10u | 1u << 16, 12u | 1u << 16, 14u | 2u << 16, 18u | 2u << 16,
+    22u | 3u << 16, 30u | 3u << 16, 38u | 4u << 16, 54u | 4u << 16, 70u | 5u << 16, 102u | 5u << 16,
+    134u | 6u << 16, 198u | 7u << 16, 326u | 8u << 16, 582u | 9u << 16, 1094u | 10u << 16, 2118u | 24u << 16};
+
+// order in which the code-length-code lengths are stored (BrotligHuffmanTable.cpp:40-42)
+__device__ static const uint8_t kCodeLenOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+
+// ---- LDS layout: one of these per 32-lane half ---------------------------------------------
+struct __attribute__((aligned(16))) PageLds {
+    uint16_t lut_icp[1 << kLutBitsIcp];
+    uint16_t lut_dist[1 << kLutBitsDist];
+    uint16_t lut_lit[1 << kLutBitsLit];
+    uint16_t sorted_icp[kIcpAlphabet];
+    uint16_t sorted_dist[kDistAlphabet];
+    uint16_t sorted_lit[kLitAlphabet];
+    uint16_t limit[3][16];      // per code length: exclusive upper bound, left-justified to 15 bits
+    uint16_t first[3][16];      // first code of the length, left-justified
+    uint16_t offs[3][16];       // index of the first symbol of the length in sorted_*
+    uint32_t round_ins_incl[32];    // per round: inclusive prefix of insert lengths
+    uint32_t round_copy_excl[32];   // per round: exclusive prefix of copy lengths
+    uint8_t  lens[kIcpAlphabet];    // code lengths of the table being built
+    uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
+};
+
+struct __attribute__((aligned(16))) WaveLds {
+    PageLds  page[2];
+    uint32_t len_code_tab[48];
+};
+
+// ---- per-lane bit reader over one sub-bitstream ---------------------------------------------
+// LSB-first.  `buf` holds `avail` valid bits; `nextw` is the dword after them, already in flight.
+struct BitReader {
+    const uint8_t* base;    // page start in the input buffer
+    uint32_t limit;         // bytes readable from base (reads beyond return 0)
+    uint64_t buf;
+    uint32_t avail;
+    uint32_t next;          // byte offset of nextw, dword aligned relative to base
+    uint32_t nextw;
+
+    __device__ __forceinline__ uint32_t load(uint32_t rel) const
+    {
+        return rel < limit ? *reinterpret_cast<const uint32_t*>(base + rel) : 0u;
+    }
+    __device__ __forceinline__ void init(const uint8_t* b, uint32_t lim, uint32_t start)
+    {
+        base = b; limit = lim;
+        const uint32_t a = start & ~3u, skip = (start & 3u) * 8u;
+        buf = (uint64_t)(load(a) >> skip);
+        avail = 32u - skip;
+        next = a + 4u;
+        nextw = load(next);
+        if (avail < 32u) refill();
+    }
+    __device__ __forceinline__ void refill()
+    {
+        buf |= (uint64_t)nextw << avail;
+        avail += 32u;
+        next += 4u;
+        nextw = load(next);
+    }
+    __device__ __forceinline__ void ensure(uint32_t n) { if (avail < n) refill(); }          // n <= 32
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const                               // n <= 32
+    {
+        return n >= 32u ? (uint32_t)buf : ((uint32_t)buf & ((1u << n) - 1u));
+    }
+    __device__ __forceinline__ void consume(uint32_t n) { buf >>= n; avail -= n; }
+    __device__ __forceinline__ uint32_t read(uint32_t n)
+    {
+        if (n == 0u) return 0u;
+        ensure(n);
+        const uint32_t v = peek(n);
+        consume(n);
+        return v;
+    }
+};
+
+__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t bit_width_u32(uint32_t x) { return x ? 32u - (uint32_t)__clz((int)x) : 0u; }
+__device__ __forceinline__ uint32_t ctz_u32(uint32_t x) { return (uint32_t)__ffs((int)x) - 1u; }      // x != 0
+__device__ __forceinline__ uint32_t msb_u32(uint32_t x) { return 31u - (uint32_t)__clz((int)x); }     // x != 0
+__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+
+// One prefix-code table: which LDS arrays it lives in.
+struct TableRef {
+    uint16_t* lut; uint16_t* sorted; uint16_t* limit; uint16_t* first; uint16_t* offs;
+    uint32_t alphabet; int lut_bits;
+};
+
+// Decode one symbol from `br` (needs avail >= 15 on entry).  Returns symbol, sets len.
+__device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitReader& br, uint32_t& len)
+{
+    const uint32_t bits = (uint32_t)br.buf;
+    const uint32_t e = t.lut[bits & ((1u << t.lut_bits) - 1u)];
+    if (e != kLongCode) { len = e & 15u; return e >> 4; }
+    // canonical fallback for codes longer than the LUT index
+    const uint32_t v = __brev(bits) >> 17;                      // next 15 bits, MSB-first
+    uint32_t l = (uint32_t)t.lut_bits + 1u;
+    while (l < 15u && v >= t.limit[l]) ++l;
+    uint32_t idx = t.offs[l] + ((v - t.first[l]) >> (15u - l));
+    idx = min_u32(idx, t.alphabet - 1u);
+    len = l;
+    return t.sorted[idx];
+}
+
+// -------------------------------------------------------------------------------------------
+// Prefix-code description -> decode tables (format: SURVEY.md A.5; reference reader:
+// src/decoder/BrotligHuffmanTable.cpp:73-205).  Runs for both halves at once; `live` says
+// whether this half has a compressed page.
+__device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br, bool live, uint32_t sl)
+{
+    const uint32_t A = t.alphabet;
+    const uint32_t maxbits = bit_width_u32(A - 1u);
+    const uint32_t lut_size = 1u << t.lut_bits;
+    uint16_t* scratch16 = t.lut;            // LUT area doubles as scratch until the LUT itself is written
+
+    // -- header: lane 0 of the half reads 6 bits from sub-stream 0
+    uint32_t hdr = 0;
+    if (live && sl == 0u) hdr = br.read(6);
+    hdr = wave::half_shfl(hdr, 0);
+    const uint32_t type = hdr & 3u;
+    const bool is_trivial = live && type == 0u;
+    const bool is_simple = live && type == 1u;
+    const bool is_complex = live && type >= 2u;    // type 3 is invalid; treated as complex, fails bounds later
+
+    // -- trivial / simple: up to 4 symbols, symbol k from sub-stream k
+    const uint32_t nsym = is_trivial ? 1u : ((hdr >> 2) & 3u) + 1u;
+    const uint32_t tree_select = (hdr >> 4) & 1u;
+    uint32_t mysym = 0;
+    if ((is_trivial || is_simple) && sl < nsym) mysym = br.read(maxbits);
+    const uint32_t s0 = wave::half_shfl(mysym, 0), s1 = wave::half_shfl(mysym, 1);
+    const uint32_t s2 = wave::half_shfl(mysym, 2), s3 = wave::half_shfl(mysym, 3);
+    // -- complex: code-length code, then RLE-coded code lengths
+    if (wave::any(is_complex)) {
+        // 18 code-length-code lengths, the k-th from sub-stream k, for symbols in a fixed order
+        const uint32_t ncl = min_u32(((hdr >> 2) & 15u) + 4u, 18u);
+        uint32_t cl_len = 0;
+        const uint32_t cl_sym = sl < 18u ? kCodeLenOrder[sl] : 31u;
+        if (is_complex && sl < ncl) cl_len = br.read(5);
+        if (cl_len > 9u) cl_len = 0u;                              // > 9 is invalid (2^9 table in the reference)
+        // canonical code of my code-length symbol: sum over symbols that precede it in (length, symbol) order
+        uint32_t cl_code = 0;
+        for (uint32_t j = 0; j < 18u; ++j) {
+            const uint32_t lj = wave::half_shfl(cl_len, j), sj = wave::half_shfl(cl_sym, j);
+            if (cl_len && lj && (lj < cl_len || (lj == cl_len && sj < cl_sym))) cl_code += 1u << (cl_len - lj);
+        }
+        // 9-bit LUT: entry = sym << 4 | len, index = next 9 stream bits (LSB-first)
+        if (is_complex) for (uint32_t e = sl; e < 512u; e += 32u) scratch16[e] = 0;
+        wave::sync();
+        {
+            const uint32_t reps = (is_complex && sl < 18u && cl_len) ? (1u << (9u - cl_len)) : 0u;
+            const uint32_t rcode = cl_len ? (__brev(cl_code) >> (32u - cl_len)) : 0u;
+            for (uint32_t m = 0; m < reps; ++m) scratch16[rcode + (m << cl_len)] = (uint16_t)((cl_sym << 4) | cl_len);
+        }
+        wave::sync();
+
+        // RLE symbols: one (plus its extra bits) per sub-stream, round-robin, until A lengths exist
+        uint32_t produced = is_complex ? 0u : A;
+        uint32_t prev_len = 8;                                     // BROTLI_INITIAL_REPEATED_CODE_LENGTH
+        while (wave::any(produced < A)) {
+            const bool act = produced < A;
+            uint32_t sym = 0, clen = 0, run = 0, extra = 0, nextra = 0;
+            if (act) {
+                br.ensure(16);                                     // 9-bit code + up to 3 extra bits
+                const uint32_t e = scratch16[br.peek(9)];
+                sym = e >> 4; clen = e & 15u;
+                nextra = sym == 16u ? 2u : (sym == 17u ? 3u : 0u);
+                extra = ((uint32_t)(br.buf >> clen)) & ((1u << nextra) - 1u);
+                run = sym >= 16u ? 3u + extra : 1u;
+            }
+            const uint32_t incl = wave::half_scan_incl(run);
+            const uint32_t start = produced + incl - run;
+            const bool valid = act && start < A;
+            if (valid) br.consume(clen + nextra);
+            const uint32_t lit_mask = wave::half_ballot(valid && sym < 16u);
+            const uint32_t before = lit_mask & ((1u << sl) - 1u);
+            const uint32_t from_lane = wave::half_shfl(sym, before ? msb_u32(before) : 0u);
+            const uint32_t last_lit = wave::half_shfl(sym, lit_mask ? msb_u32(lit_mask) : 0u);
+            uint32_t value = sym;                                  // literal length
+            if (sym == 17u) value = 0u;
+            else if (sym == 16u) value = before ? from_lane : prev_len;    // repeat previous *literal* length
+            if (valid) {
+                const uint32_t end = min_u32(start + run, A);
+                for (uint32_t s = start; s < end; ++s) L.lens[s] = (uint8_t)value;
+            }
+            produced = min_u32(A, produced + wave::half_sum(valid ? run : 0u));
+            if (lit_mask) prev_len = last_lit;
+        }
+        wave::sync();
+
+        // canonical build.  Each lane owns a contiguous block of symbols; per-(length, lane)
+        // counters give every symbol its rank without atomics.
+        uint16_t* cnt = scratch16;                                 // [16][32]
+        const uint32_t blk = (A + 31u) / 32u;
+        const uint32_t b0 = sl * blk, b1 = min_u32(A, b0 + blk);
+        if (is_complex) for (uint32_t l = 0; l < 16u; ++l) cnt[l * 32u + sl] = 0;
+        wave::sync();
+        if (is_complex)
+            for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = L.lens[s] & 15u; if (l) cnt[l * 32u + sl]++; }
+        wave::sync();
+        uint32_t code = 0, off = 0, prev_count = 0;
+        for (uint32_t l = 1; l < 16u; ++l) {
+            const uint32_t c = is_complex ? cnt[l * 32u + sl] : 0u;
+            const uint32_t incl = wave::half_scan_incl(c);
+            const uint32_t total = wave::half_shfl(incl, 31);
+            if (is_complex) cnt[l * 32u + sl] = (uint16_t)(off + incl - c);
+            code = (code + prev_count) << 1;
+            if (is_complex && sl == 0u) {
+                t.first[l] = (uint16_t)min_u32(code << (15u - l), 32768u);
+                t.limit[l] = (uint16_t)min_u32((code + total) << (15u - l), 32768u);
+                t.offs[l] = (uint16_t)off;
+            }
+            off += total; prev_count = total;
+        }
+        wave::sync();
+        if (is_complex)
+            for (uint32_t s = b0; s < b1; ++s) {
+                const uint32_t l = L.lens[s] & 15u;
+                if (l) { const uint32_t p = cnt[l * 32u + sl]++; t.sorted[min_u32(p, A - 1u)] = (uint16_t)s; }
+            }
+        wave::sync();
+        // primary LUT, one entry per lane per step
+        if (is_complex) {
+            for (uint32_t e = sl; e < lut_size; e += 32u) {
+                const uint32_t v = __brev(e) >> 17;                // LUT index bits as a left-justified 15-bit code prefix
+                uint32_t l = 1;
+                while (l <= (uint32_t)t.lut_bits && v >= t.limit[l]) ++l;
+                uint32_t entry = kLongCode;
+                if (l <= (uint32_t)t.lut_bits) {
+                    uint32_t idx = t.offs[l] + ((v - t.first[l]) >> (15u - l));
+                    idx = min_u32(idx, A - 1u);
+                    entry = ((uint32_t)t.sorted[idx] << 4) | l;
+                }
+                t.lut[e] = (uint16_t)entry;
+            }
+        }
+    }
+    // -- trivial / simple LUTs (written last: the complex path uses LUT areas as scratch)
+    if (is_trivial) {
+        for (uint32_t e = sl; e < lut_size; e += 32u) t.lut[e] = (uint16_t)(s0 << 4);
+    } else if (is_simple) {
+        const uint32_t shape = nsym < 4u ? nsym - 2u : (tree_select ? 3u : 2u);   // BrotligHuffmanTable.cpp:26-38
+        for (uint32_t e = sl; e < lut_size; e += 32u) {
+            const uint32_t b0 = e & 1u, b1 = (e >> 1) & 1u, b2 = (e >> 2) & 1u;
+            uint32_t k, len;
+            if (shape == 0u) { k = b0; len = 1u; }
+            else if (shape == 1u) { k = b0 ? 1u + b1 : 0u; len = b0 ? 2u : 1u; }
+            else if (shape == 2u) { k = b0 * 2u + b1; len = 2u; }
+            else { k = !b0 ? 0u : (!b1 ? 1u : 2u + b2); len = !b0 ? 1u : (!b1 ? 2u : 3u); }
+            const uint32_t sym = k == 0u ? s0 : k == 1u ? s1 : k == 2u ? s2 : s3;
+            t.lut[e] = (uint16_t)((sym << 4) | len);
+        }
+    }
+    wave::sync();
+}
+
+// -------------------------------------------------------------------------------------------
+// Decode the pages `page_a` (lanes 0-31) and `page_b` (lanes 32-63); either may be absent.
+struct PageJob {
+    const uint8_t* in;      // compressed page
+    uint32_t in_size;       // bytes
+    uint32_t in_limit;      // bytes readable from `in` without leaving the input buffer
+    uint8_t* out;           // where the page's bytes go (final output, or conditioned-space scratch)
+    uint32_t out_size;
+    uint32_t page_size;
+    uint32_t page_off;      // offset of the page in its stream's (conditioned) byte space
+    const DcTable* dc;      // non-null for preconditioned streams
+    bool     valid;
+};
+
+__device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t* status)
+{
+    const uint32_t lane = wave::lane_id();
+    const uint32_t sl = lane & 31u;
+    PageLds& L = W.page[lane >> 5];
+
+    const bool stored = job.valid && job.in_size == job.out_size;       // PageDecoder.cpp:70-76
+    bool live = job.valid && !stored;
+
+    // ---- stored page: plain copy, 4 bytes per lane per step
+    if (stored) {
+        const uint32_t words = job.out_size >> 2;
+        for (uint32_t i = sl; i < words; i += 32u)
+            reinterpret_cast<uint32_t*>(job.out)[i] = load_u32(job.in + 4u * i);
+        for (uint32_t i = (words << 2) + sl; i < job.out_size; i += 32u) job.out[i] = job.in[i];
+    }
+
+    // ---- page header + sub-stream size table (PageDecoder.cpp:79-121)
+    uint32_t npostfix = 0, ndirect = 0;
+    bool is_delta = false;
+    BitReader br;
+    br.base = job.in; br.limit = 0; br.buf = 0; br.avail = 64; br.next = 0; br.nextw = 0;
+    {
+        uint32_t my_len = 0, hdr_bytes = 0;
+        if (live) {
+            const uint32_t w0 = load_u32(job.in), w1 = load_u32(job.in + 4);
+            const uint64_t h = (uint64_t)w0 | ((uint64_t)w1 << 32);
+            npostfix = (uint32_t)h & 3u;
+            ndirect = (((uint32_t)h >> 2) & 15u) << npostfix;
+            is_delta = (((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr;       // PageDecoder.cpp:87-88
+            const uint32_t base_bits = bit_width_u32((job.in_size + 31u) / 32u);
+            const uint32_t dsize_bits = bit_width_u32(bit_width_u32(job.in_size - 1u));
+            const uint32_t base_size = (uint32_t)(h >> 8) & ((1u << base_bits) - 1u);
+            const uint32_t delta_bits = (uint32_t)(h >> (8u + base_bits)) & ((1u << dsize_bits) - 1u);
+            const uint32_t table_at = 8u + base_bits + dsize_bits;
+            const uint32_t bit = table_at + sl * delta_bits;
+            const uint32_t wi = (bit >> 5) * 4u;
+            const uint64_t d = (uint64_t)load_u32(job.in + wi) | ((uint64_t)load_u32(job.in + wi + 4u) << 32);
+            const uint32_t delta = (uint32_t)(d >> (bit & 31u)) & ((1u << delta_bits) - 1u);
+            my_len = base_size + delta;
+            hdr_bytes = ((table_at + 32u * delta_bits + 31u) / 32u) * 4u;
+        }
+        const uint32_t incl = wave::half_scan_incl(my_len);
+        if (live) br.init(job.in, job.in_limit, hdr_bytes + incl - my_len);
+    }
+
+    // ---- three prefix codes: ICP, distance, literal (PageDecoder.cpp:125-147)
+    const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first[0], L.offs[0], kIcpAlphabet, kLutBitsIcp};
+    const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first[1], L.offs[1], kDistAlphabet, kLutBitsDist};
+    const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first[2], L.offs[2], kLitAlphabet, kLutBitsLit};
+    build_table(t_icp, L, br, live, sl);
+    build_table(t_dist, L, br, live, sl);
+    build_table(t_lit, L, br, live, sl);
+
+    // ---- rounds (PageDecoder.cpp:174-236; format A.6)
+    uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16;             // PageDecoder.cpp:150-153
+    uint32_t out_pos = 0;            // bytes of the page produced so far
+    uint32_t prev_tail = 0;          // literals decoded but not yet consumed
+    uint32_t carry_head = 0;
+    uint32_t rounds_left = job.page_size / 64u + 4u;                    // every full round emits >= 64 bytes
+    bool bad = false;
+
+    while (wave::any(live)) {
+        // -- 1. one command per lane
+        uint32_t sym = 0, len = 0;
+        if (live) { br.ensure(15); sym = decode_symbol(t_icp, br, len); }
+        const uint32_t sent_mask = wave::half_ballot(live && sym == kSentinel);
+        const uint32_t n = sent_mask ? ctz_u32(sent_mask) : 32u;
+        const bool is_cmd = live && sl < n;
+        if (live && sl <= n) br.consume(len);                           // the sentinel's own bits are consumed too
+
+        uint32_t ins = 0, copy = 0, dist = 0, dcode = 0;
+        if (is_cmd) {
+            if (sym < kSentinel) {
+                const uint32_t cell = sym >> 6;
+                const uint32_t ic = ((0x298500u >> (2u * cell)) & 3u) * 8u + ((sym >> 3) & 7u);
+                const uint32_t cc = ((0x262444u >> (2u * cell)) & 3u) * 8u + (sym & 7u);
+                const uint32_t it = W.len_code_tab[ic], ct = W.len_code_tab[24u + cc];
+                ins = (it & 0xFFFFu) + br.read(it >> 16);
+                copy = (ct & 0xFFFFu) + br.read(ct >> 16);
+                if (sym >= 128u) {                                      // explicit distance symbol
+                    uint32_t dl;
+                    br.ensure(15);
+                    dcode = decode_symbol(t_dist, br, dl);
+                    br.consume(dl);
+                    if (dcode >= 16u) {                                 // PageDecoder.cpp:365-390
+                        if (dcode < 16u + ndirect) dist = dcode - 15u;
+                        else {
+                            const uint32_t x = dcode - ndirect - 16u;
+                            const uint32_t nbits = min_u32(1u + (x >> (npostfix + 1u)), 24u);
+                            const uint32_t extra = br.read(nbits);
+                            const uint32_t hcode = x >> npostfix, lcode = x & ((1u << npostfix) - 1u);
+                            dist = ((((2u + (hcode & 1u)) << nbits) - 4u + extra) << npostfix) + lcode + ndirect + 1u;
+                        }
+                    }
+                }
+            } else {                                                    // insert-only, PageDecoder.cpp:308-317
+                const uint32_t it = W.len_code_tab[min_u32(sym - kSentinel, 23u)];
+                ins = (it & 0xFFFFu) + br.read(it >> 16);
+            }
+        }
+
+        // -- 2. distance ring (PageDecoder.cpp:345-364, :396-403): codes 1..15 are resolved in
+        //       command order; explicit distances and code 0 need no serial step
+        const bool is_copy = is_cmd && copy > 0u;
+        const uint32_t push_mask = wave::half_ballot(is_copy && dcode != 0u);
+        uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
+        while (wave::any(pend != 0u)) {
+            const uint32_t k = pend ? ctz_u32(pend) : 0u;
+            const uint32_t kd = wave::half_shfl(dcode, k);
+            const uint32_t r = kd < 4u ? kd : (kd < 10u ? 0u : 1u);
+            uint32_t below = push_mask & ((1u << k) - 1u);
+            const uint32_t cnt = (uint32_t)__popc(below);
+            for (uint32_t i = 0; i < r && below; ++i) below &= ~(1u << msb_u32(below));
+            const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
+            uint32_t val;
+            if (r < cnt) val = from;
+            else { const uint32_t q = r - cnt; val = q == 0u ? ring0 : q == 1u ? ring1 : q == 2u ? ring2 : ring3; }
+            if (kd >= 4u) {
+                const uint32_t j = (kd - 4u) % 6u, mag = (j >> 1) + 1u;
+                val = (j & 1u) ? val + mag : val - mag;
+            }
+            if (pend && sl == k) dist = val;
+            pend &= pend - 1u;
+        }
+        {
+            const uint32_t below = push_mask & ((1u << sl) - 1u);
+            const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
+            if (is_copy && dcode == 0u) dist = below ? from : ring0;
+            // new ring = the last four pushed distances
+            uint32_t m = push_mask;
+            const uint32_t cnt = (uint32_t)__popc(m);
+            uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+            if (m) { l0 = msb_u32(m); m &= ~(1u << l0); }
+            if (m) { l1 = msb_u32(m); m &= ~(1u << l1); }
+            if (m) { l2 = msb_u32(m); m &= ~(1u << l2); }
+            if (m) { l3 = msb_u32(m); }
+            const uint32_t d0 = wave::half_shfl(dist, l0), d1 = wave::half_shfl(dist, l1);
+            const uint32_t d2 = wave::half_shfl(dist, l2), d3 = wave::half_shfl(dist, l3);
+            const uint32_t o0 = ring0, o1 = ring1, o2 = ring2;
+            if (cnt >= 4u) { ring0 = d0; ring1 = d1; ring2 = d2; ring3 = d3; }
+            else if (cnt == 3u) { ring0 = d0; ring1 = d1; ring2 = d2; ring3 = o0; }
+            else if (cnt == 2u) { ring0 = d0; ring1 = d1; ring2 = o0; ring3 = o1; }
+            else if (cnt == 1u) { ring0 = d0; ring1 = o0; ring2 = o1; ring3 = o2; }
+        }
+
+        // -- 3. output positions
+        const uint32_t tot = ins + copy;
+        const uint32_t incl_tot = wave::half_scan_incl(tot);
+        const uint32_t incl_ins = wave::half_scan_incl(ins);
+        const uint32_t round_bytes = wave::half_shfl(incl_tot, 31);
+        const uint32_t litcount = wave::half_shfl(incl_ins, 31);
+        const uint32_t cmd_out = out_pos + incl_tot - tot;              // first literal of my command
+        const uint32_t copy_dst = cmd_out + ins;
+        if (live) {
+            --rounds_left;
+            if (round_bytes > job.out_size - out_pos || rounds_left == 0u) { bad = true; live = false; }
+        }
+        const bool ok_cmd = is_cmd && live;
+
+        L.round_ins_incl[sl] = incl_ins;
+        L.round_copy_excl[sl] = (incl_tot - tot) - (incl_ins - ins);
+        wave::sync();
+
+        // -- 4. literals: literal j of the round comes from sub-stream j mod 32 and is the
+        //       (prev_tail + j)-th literal the round's commands consume (PageDecoder.cpp:196-206)
+        if (live) {
+            const uint32_t ac = litcount > prev_tail ? litcount - prev_tail : 0u;
+            const uint32_t mult = n ? (ac + n - 1u) / n : 0u;
+            const uint32_t rlit = n * mult;
+            const uint32_t from_carry = min_u32(prev_tail, litcount);
+            const uint32_t new_head = carry_head + from_carry;
+            const uint32_t kept = prev_tail - from_carry;               // stays in the ring (only when rlit == 0)
+            // literals decoded in earlier rounds
+            if (sl < from_carry) {
+                const uint32_t f = sl;
+                uint32_t c = 0;
+                for (uint32_t s = 16; s; s >>= 1) if (L.round_ins_incl[c + s - 1u] <= f) c += s;
+                job.out[out_pos + f + L.round_copy_excl[c]] = L.carry[(carry_head + f) & 63u];
+            }
+            for (uint32_t j = sl; j < rlit; j += 32u) {
+                uint32_t ll;
+                br.ensure(15);
+                const uint32_t lit = decode_symbol(t_lit, br, ll);
+                br.consume(ll);
+                const uint32_t f = prev_tail + j;
+                if (f < litcount) {
+                    uint32_t c = 0;
+                    for (uint32_t s = 16; s; s >>= 1) if (L.round_ins_incl[c + s - 1u] <= f) c += s;
+                    job.out[out_pos + f + L.round_copy_excl[c]] = (uint8_t)lit;
+                } else {
+                    L.carry[(new_head + kept + (f - litcount)) & 63u] = (uint8_t)lit;
+                }
+            }
+            carry_head = new_head;
+            prev_tail = rlit + prev_tail - litcount;
+        }
+
+        // -- 5. LZ77 copies in dependency levels.  A copy is ready once its source range ends at or
+        //       below the destination of the first unfinished copy; a copy never depends on itself
+        //       because overlapping sources are read modulo the distance.
+        const bool do_copy = ok_cmd && copy > 0u;
+        const bool dist_ok = dist != 0u && dist <= copy_dst;
+        if (do_copy && !dist_ok) bad = true;
+        uint32_t todo = wave::half_ballot(do_copy && dist_ok);
+        const uint32_t src_end = copy_dst - dist + min_u32(copy, dist);
+        wave::global_fence();                                           // this round's literals, earlier rounds' bytes
+        while (wave::any(todo != 0u)) {
+            const uint32_t first_dst = wave::half_shfl(copy_dst, todo ? ctz_u32(todo) : 0u);
+            const bool mine = ((todo >> sl) & 1u) != 0u;
+            const bool ready = mine && src_end <= first_dst;
+            const uint32_t ready_mask = wave::half_ballot(ready);
+            uint32_t long_mask = wave::half_ballot(ready && copy > kShortCopy);
+            if (ready && copy <= kShortCopy) {                          // one lane per command
+                uint8_t* d = job.out + copy_dst;
+                const uint8_t* s = d - dist;
+                uint32_t r = 0;
+                for (uint32_t i = 0; i < copy; ++i) { d[i] = s[r]; if (++r == dist) r = 0; }
+            }
+            while (wave::any(long_mask != 0u)) {                        // all 32 lanes per command
+                const uint32_t k = long_mask ? ctz_u32(long_mask) : 0u;
+                const uint32_t cd = wave::half_shfl(copy_dst, k), dd = wave::half_shfl(dist, k);
+                const uint32_t cl = wave::half_shfl(copy, k);
+                if (long_mask) {
+                    uint8_t* d = job.out + cd;
+                    const uint8_t* s = d - dd;
+                    uint32_t r = dd > sl ? sl : sl % dd;
+                    const uint32_t step = dd > 32u ? 32u : 32u % dd;
+                    for (uint32_t j = sl; j < cl; j += 32u) { d[j] = s[r]; r += step; if (r >= dd) r -= dd; }
+                }
+                long_mask &= long_mask - 1u;
+            }
+            todo &= ~ready_mask;
+            if (wave::any(todo != 0u)) wave::global_fence();
+        }
+
+        out_pos += round_bytes;
+        if (sent_mask) live = false;
+    }
+
+    if (job.valid && !stored && out_pos != job.out_size) bad = true;      // a valid page fills its output exactly
+
+    // ---- per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): a running byte
+    //      sum over each colour range inside the page.  Lanes take contiguous chunks; a half-wave
+    //      scan of the chunk sums supplies each chunk's starting value.
+    const bool do_delta = is_delta && !bad;
+    if (wave::any(do_delta)) {
+        wave::global_fence();
+        for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
+            uint32_t lo = 0, hi = 0;
+            if (do_delta && ((job.dc->color_mask >> c) & 1u)) {
+                const uint32_t cs = job.dc->sub_stream_off[c], ce = job.dc->sub_stream_off[c + 1];
+                const uint32_t ps = job.page_off, pe = job.page_off + job.out_size;
+                if (cs < pe && ps < ce) { lo = (cs > ps ? cs : ps) - ps; hi = (ce < pe ? ce : pe) - ps; }
+            }
+            const uint32_t chunk = (hi - lo + 31u) / 32u;
+            const uint32_t a0 = min_u32(hi, lo + sl * chunk), a1 = min_u32(hi, a0 + chunk);
+            uint32_t sum = 0;
+            for (uint32_t i = a0; i < a1; ++i) sum += job.out[i];
+            const uint32_t incl = wave::half_scan_incl(sum & 0xFFu);
+            uint32_t run = (incl - (sum & 0xFFu)) & 0xFFu;
+            for (uint32_t i = a0; i < a1; ++i) { run = (run + job.out[i]) & 0xFFu; job.out[i] = (uint8_t)run; }
+        }
+    }
+    if (wave::any(bad) && bad && sl == 0u) atomicOr(status, kStatusBadPage);
+}
+
+// -------------------------------------------------------------------------------------------
+// Pre-conditioning tables (inc/common/BrotligDataConditioner.h:92-237).  `w0`/`w1` are the two
+// dwords of the PreconditionHeader; `out_size` is the stream's decompressed size, which must equal
+// the texture size (:219).
+__device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t out_size)
+{
+    const uint32_t fmt = w1 & 0xFFu;
+    // sub-block sizes per format, 4 bits each, first sub-block in the low nibble (:98-175)
+    const uint32_t sizes = fmt == 1u ? 0x422u : fmt == 2u ? 0x4228u : fmt == 3u ? 0x422611u
+                         : fmt == 4u ? 0x611u : fmt == 5u ? 0x611611u : 0x1u;
+    const uint32_t nsub = fmt == 1u ? 3u : fmt == 2u ? 4u : fmt == 3u ? 6u : fmt == 4u ? 3u : fmt == 5u ? 6u : 1u;
+    const uint32_t color = fmt == 1u ? 0x3u : fmt == 2u ? 0x6u : fmt == 3u ? 0x18u : fmt == 4u ? 0x3u : fmt == 5u ? 0x1Bu : 0u;
+    const uint32_t bb = (fmt == 1u || fmt == 4u) ? 8u : (fmt == 0u || fmt > 5u) ? 1u : 16u;
+    const uint32_t px = (fmt >= 1u && fmt <= 5u) ? 4u : 1u;
+    const bool aligned = ((w0 >> 1) & 1u) != 0u;
+    t.precon = 1; t.swizzle = w0 & 1u; t.block_bytes = bb; t.num_sub = nsub; t.color_mask = color;
+    t.num_mips = ((w1 >> 8) & 0x1Fu) + 1u;
+    uint32_t off = 0;
+    for (uint32_t i = 0; i < kMaxSubBlocks; ++i) {
+        t.sub_size[i] = i < nsub ? (sizes >> (4u * i)) & 15u : 0u;
+        t.sub_off[i] = off; off += t.sub_size[i];
+    }
+    t.w[0] = ((w0 >> 2) & 0x7FFFu) + 1u; t.h[0] = ((w0 >> 17) & 0x7FFFu) + 1u;
+    t.pitch[0] = ((w1 >> 13) & 0x7FFFFu) + 1u;
+    uint32_t mw = (t.w[0] * px) / 2u, mh = (t.h[0] * px) / 2u;
+    t.mip_off_bytes[0] = 0; t.mip_off_blocks[0] = 0; t.item_prefix[0] = 0;
+    uint32_t total = 0;
+    for (uint32_t m = 0; m < t.num_mips; ++m) {
+        if (m > 0u) {                                                   // :204-210
+            t.w[m] = (mw + px - 1u) / px; t.h[m] = (mh + px - 1u) / px;
+            const uint32_t row = t.w[m] * bb;
+            t.pitch[m] = aligned ? (row + 255u) / 256u * 256u : row;
+            mw /= 2u; mh /= 2u;
+        }
+        const uint32_t nblk = t.w[m] * t.h[m];
+        total += nblk;
+        t.mip_off_bytes[m + 1] = t.mip_off_bytes[m] + t.pitch[m] * t.h[m];
+        t.mip_off_blocks[m + 1] = t.mip_off_blocks[m] + nblk;
+        t.item_prefix[m + 1] = t.item_prefix[m] + t.h[m] * ((t.pitch[m] + bb - 1u) / bb);
+    }
+    for (uint32_t m = t.num_mips; m < kMaxMips; ++m) { t.w[m] = t.h[m] = t.pitch[m] = 0; }
+    t.total_blocks = total; t.tex_bytes = total * bb;
+    t.sub_stream_off[0] = 0;
+    for (uint32_t i = 0; i < kMaxSubBlocks; ++i) t.sub_stream_off[i + 1] = t.sub_stream_off[i] + total * t.sub_size[i];
+    if (t.pitch[0] < t.w[0] * bb) return false;
+    return t.mip_off_bytes[t.num_mips] == out_size;                     // :219
+}
+
+// Kernel 3 (preconditioned streams only): conditioned space -> texture space, as a gather.
+// The reference scatters byte by byte (PageDecoder.cpp:243-265,:406-444); here one thread owns
+// one block-sized chunk of one texture row, reads that block's sub-blocks from the conditioned
+// staging buffer and writes the chunk (or zeros for row-pitch padding, which the reference
+// leaves at the 0 of its initial memset, src/BrotligDecoder.cpp:448).
+__global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
+{
+    if (a.status[2] == 0u) return;                                      // no preconditioned stream in this batch
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t s = 0; s < a.num_streams; ++s) {
+        const DcTable& t = a.dc[s];
+        if (!t.precon) continue;
+        const uint64_t base = a.streams[s].out_offset;
+        const uint8_t* cond = a.scratch + base;
+        uint8_t* tex = a.out + base;
+        const uint32_t bb = t.block_bytes, items = t.item_prefix[t.num_mips];
+        for (uint32_t item = tid; item < items; item += nthreads) {
+            uint32_t m = 0;
+            while (item >= t.item_prefix[m + 1]) ++m;
+            const uint32_t W = t.w[m], H = t.h[m], pitch = t.pitch[m];
+            const uint32_t per_row = (pitch + bb - 1u) / bb;
+            const uint32_t in_mip = item - t.item_prefix[m];
+            const uint32_t row = in_mip / per_row, col = in_mip % per_row;
+            uint8_t* dst = tex + t.mip_off_bytes[m] + row * pitch + col * bb;
+            const uint32_t nbytes = min_u32(bb, pitch - col * bb);
+            if (col >= W) { for (uint32_t i = 0; i < nbytes; ++i) dst[i] = 0; continue; }
+            // inverse of the 2x2 de-swizzle (PageDecoder.cpp:416-436): texture (row, col) -> block index
+            uint32_t block = row * W + col;
+            const uint32_t effW = W - (W & 1u), effH = H - (H & 1u);
+            if (t.swizzle && W >= 2u && H >= 2u && row < effH && col < effW) {
+                const uint32_t eff = ((row >> 1) * (effW >> 1) + (col >> 1)) * 4u + (row & 1u) * 2u + (col & 1u);
+                block = (eff / effW) * W + eff % effW;
+            }
+            for (uint32_t sub = 0; sub < t.num_sub; ++sub) {
+                const uint32_t sz = t.sub_size[sub];
+                const uint8_t* src = cond + t.sub_stream_off[sub] + (t.mip_off_blocks[m] + block) * sz;
+                uint8_t* d = dst + t.sub_off[sub];
+                for (uint32_t i = 0; i < sz; ++i) d[i] = src[i];
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// Kernel 1: page counts per stream -> exclusive prefix (one workgroup; streams <= a few thousand)
+__global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
+{
+    const uint32_t lane = threadIdx.x;
+    uint32_t running = 0;
+    for (uint32_t base = 0; base < a.num_streams; base += 64u) {
+        const uint32_t s = base + lane;
+        uint32_t pages = 0;
+        if (s < a.num_streams) {
+            const uint8_t* p = a.in + a.streams[s].in_offset;
+            StreamInfo si;
+            if (parse_stream_header(load_u32(p), load_u32(p + 4), si)) pages = si.num_pages;
+            else atomicOr(a.status, kStatusBadHeader);
+            DcTable& t = a.dc[s];
+            t.precon = 0;
+            if (pages && si.preconditioned) {
+                if (!dc_init(t, load_u32(p + 8), load_u32(p + 12), uncompressed_size(si)) || a.scratch == nullptr) {
+                    t.precon = 0; pages = 0;                            // the reference has undefined behaviour here
+                    atomicOr(a.status, kStatusBadHeader);
+                } else atomicAdd(a.status + 2, 1u);
+            }
+        }
+        const uint32_t lo = wave::half_scan_incl(pages);
+        const uint32_t lo_total = wave::half_shfl(lo, 31);
+        const uint32_t first_half_total = wave::bcast(lo_total, 0);
+        const uint32_t second_half_total = wave::bcast(lo_total, 32);
+        const uint32_t incl = lane < 32u ? lo : lo + first_half_total;
+        if (s < a.num_streams) a.page_base[s] = running + incl - pages;
+        running += first_half_total + second_half_total;
+    }
+    if (lane == 0u) { a.page_base[a.num_streams] = running; a.work_counter[0] = 0u; }
+}
+
+// Kernel 2: persistent waves pull page pairs until the counter runs out.
+__global__ void __launch_bounds__(64) brotlig_decode_kernel(DecodeArgs a)
+{
+    __shared__ WaveLds W;
+    const uint32_t lane = wave::lane_id();
+    if (lane < 48u) W.len_code_tab[lane] = kLenCodeTab[lane];
+    wave::sync();
+    const uint32_t total = a.page_base[a.num_streams];
+
+    for (;;) {
+        uint32_t g0 = 0;
+        if (lane == 0u) g0 = atomicAdd(a.work_counter, 2u);
+        g0 = wave::bcast(g0, 0);
+        if (g0 >= total) break;                                         // uniform: same value in every lane
+        const uint32_t g = g0 + (lane >> 5);
+
+        PageJob job;
+        job.valid = g < total;
+        job.in = a.in; job.out = a.out; job.in_size = job.out_size = 0; job.in_limit = 0; job.page_size = kMinPageSize;
+        job.page_off = 0; job.dc = nullptr;
+        if (job.valid) {
+            // stream lookup: largest s with page_base[s] <= g
+            uint32_t lo = 0, hi = a.num_streams;
+            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (a.page_base[mid] <= g) lo = mid; else hi = mid; }
+            const uint32_t i = g - a.page_base[lo];
+            const uint64_t s_in = a.streams[lo].in_offset, s_out = a.streams[lo].out_offset;
+            const uint8_t* sp = a.in + s_in;
+            StreamInfo si;
+            parse_stream_header(load_u32(sp), load_u32(sp + 4), si);
+            const uint8_t* table = sp + si.header_bytes;
+            const uint8_t* pages = table + 4u * si.num_pages;
+            const uint32_t off = i ? load_u32(table + 4u * i) : 0u;                      // src/BrotligDecoder.cpp:310
+            job.in_size = i + 1u < si.num_pages ? load_u32(table + 4u * (i + 1u)) - off : load_u32(table);   // :311
+            job.out_size = (i + 1u == si.num_pages && si.last_page_size) ? si.last_page_size : si.page_size;  // :314
+            job.page_size = si.page_size;
+            job.in = pages + off;
+            const uint64_t abs_in = (uint64_t)(job.in - a.in);
+            const uint64_t room = abs_in < a.in_bytes ? a.in_bytes - abs_in : 0;
+            job.in_limit = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ((room + 3ull) & ~3ull));
+            const uint64_t abs_out = s_out + (uint64_t)i * si.page_size;
+            uint8_t* dst_base = si.preconditioned ? a.scratch : a.out;
+            job.page_off = i * si.page_size;
+            job.dc = si.preconditioned ? &a.dc[lo] : nullptr;
+            job.out = dst_base + abs_out;
+            if (abs_out + job.out_size > a.out_bytes || job.in_size > room || dst_base == nullptr) {
+                job.valid = false;
+                atomicOr(a.status, kStatusBadPage);
+            }
+        }
+        decode_page_pair(W, job, a.status);
+    }
+}
+
+// Device self-test of the cross-lane primitives (results checked on the host).
+__global__ void __launch_bounds__(64) brotlig_selftest_kernel(uint32_t* out)
+{
+    const uint32_t lane = wave::lane_id();
+    const uint32_t v = (lane * 2654435761u) >> 24;
+    out[lane] = wave::half_scan_incl(v);
+    out[64 + lane] = wave::half_scan_incl_ref(v);
+    out[128 + lane] = wave::half_ballot((v & 1u) != 0u);
+    out[192 + lane] = wave::half_shfl(v, lane * 7u + 3u);
+    out[256 + lane] = wave::half_max(v);
+    out[320 + lane] = v;
+}
+
+}  // namespace brotlig

@@ -29,35 +29,36 @@ _VOCAB_CACHE = {}
 
 
 def _vocab(seed):
+    """4096 pseudo-words as (flat bytes, offsets, lengths)."""
     if seed not in _VOCAB_CACHE:
         rng = np.random.default_rng(1000 + seed)
         letters = np.frombuffer(b"etaoinshrdlucmfwypvbgkqjxz", dtype=np.uint8)
         p = np.arange(1, 27, dtype=np.float64) ** -0.9
         p /= p.sum()
-        words = []
-        for _ in range(4096):
-            ln = int(rng.integers(2, 11))
-            words.append(bytes(rng.choice(letters, ln, p=p)))
-        _VOCAB_CACHE[seed] = words
+        lens = rng.integers(2, 11, 4096)
+        flat = rng.choice(letters, int(lens.sum()), p=p)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        _VOCAB_CACHE[seed] = (flat, offs, lens)
     return _VOCAB_CACHE[seed]
 
 
 def text(n, seed=0):
     """Word soup: Zipf over a 4k-word vocabulary with punctuation and line breaks."""
     rng = np.random.default_rng(seed)
-    words = _vocab(seed % 4)
-    ranks = np.minimum(rng.zipf(1.25, n // 4 + 64) - 1, len(words) - 1)
-    seps = rng.choice(np.frombuffer(b"     ,.\n;", dtype=np.uint8), len(ranks))
-    parts = []
-    total = 0
-    for r, s in zip(ranks, seps):
-        w = words[r]
-        parts.append(w)
-        parts.append(bytes([s]))
-        total += len(w) + 1
-        if total >= n:
-            break
-    return np.frombuffer(b"".join(parts), dtype=np.uint8)[:n].copy()
+    flat, offs, lens = _vocab(seed % 4)
+    nw = n // 3 + 64
+    ranks = np.minimum(rng.zipf(1.25, nw) - 1, 4095)
+    seps = rng.choice(np.frombuffer(b"     ,.\n;", dtype=np.uint8), nw)
+    wl = lens[ranks] + 1                                  # word + separator
+    starts = np.concatenate([[0], np.cumsum(wl)[:-1]])
+    total = int(wl.sum())
+    word_id = np.repeat(np.arange(nw), wl)
+    within = np.arange(total) - starts[word_id]
+    is_sep = within == (wl[word_id] - 1)
+    src = offs[ranks][word_id] + np.minimum(within, lens[ranks][word_id] - 1)
+    out = flat[src]
+    out[is_sep] = seps[word_id[is_sep]]
+    return out[:n].copy()
 
 
 def records(n, seed=0):
@@ -167,3 +168,30 @@ def bc_texture(fmt, width_blocks, height_blocks, seed=0, num_mips=1, pitch_bytes
         chunks.append(tex.reshape(-1))
     data = np.concatenate(chunks)
     return data
+
+
+def tile_stream(stream, repeat):
+    """Builds a stream whose page list is the page list of `stream` repeated `repeat` times.
+    Pages are independent (no cross-page references, one set of prefix codes per page), so any
+    concatenation with a rebuilt page table is a valid stream.  Only for
+    non-preconditioned streams whose last page is full."""
+    s = np.ascontiguousarray(stream, dtype=np.uint8)
+    n = int(s[2]) | (int(s[3]) << 8)
+    w1 = int(s[4:8].view("<u4")[0])
+    assert (w1 >> 20) & 1 == 0 and ((w1 >> 2) & 0x3FFFF) == 0, "tile_stream needs full, unconditioned pages"
+    table = s[8:8 + 4 * n].view("<u4").astype(np.int64)
+    data = s[8 + 4 * n:]
+    offs = table.copy()
+    offs[0] = 0
+    last_size = int(table[0])
+    body_len = int(offs[-1]) + last_size if n > 1 else last_size
+    body = data[:body_len]
+    N = n * repeat
+    assert N <= 65535
+    new_offs = (offs[None, :] + (np.arange(repeat, dtype=np.int64) * body_len)[:, None]).reshape(-1)
+    new_table = new_offs.astype("<u4")
+    new_table[0] = last_size
+    hdr = s[:8].copy()
+    hdr[2] = N & 0xFF
+    hdr[3] = N >> 8
+    return np.concatenate([hdr, new_table.view(np.uint8), np.tile(body, repeat)])

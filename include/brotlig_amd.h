@@ -1,0 +1,116 @@
+/*
+ * brotlig_amd.h -- C ABI of the MI355X-native Brotli-G decompressor (libbrotlig_hip.so).
+ *
+ * Drop-in boundary for the GPU decode path of GPUOpen brotli_g_sdk 1.1.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference tree).  Plain
+ * pointers and sizes only; no C++ or torch types cross this boundary.  There is no CPU decode
+ * path in this library: if no HIP device is usable every decode entry fails with
+ * BROTLIG_ERROR_GENERIC.
+ */
+#ifndef BROTLIG_AMD_H
+#define BROTLIG_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* inc/common/BrotligCommon.h:50-68 -- same enumerators, same numeric values */
+typedef enum BROTLIG_ERROR {
+    BROTLIG_OK = 0,
+    BROTLIG_ABORTED,
+    BROTLIG_ERROR_MIN_PAGE_SIZE,
+    BROTLIG_ERROR_MAX_PAGE_SIZE,
+    BROTLIG_ERROR_MAX_NUM_PAGES,
+    BROTLIG_ERROR_PRECON_MIN_TEX_WIDTH,
+    BROTLIG_ERROR_PRECON_MAX_TEX_WIDTH,
+    BROTLIG_ERROR_PRECON_MIN_TEX_HEIGHT,
+    BROTLIG_ERROR_PRECON_MAX_TEX_HEIGHT,
+    BROTLIG_ERROR_PRECON_MIN_TEX_PITCH,
+    BROTLIG_ERROR_PRECON_MAX_TEX_PITCH,
+    BROTLIG_ERROR_PRECON_MIN_TEX_MIPLEVELS,
+    BROTLIG_ERROR_PRECON_MAX_TEX_MIPLEVELS,
+    BROTLIG_ERROR_PRECON_INCORRECT_FORMAT,
+    BROTLIG_ERROR_CORRUPT_STREAM,
+    BROTLIG_ERROR_INCORRECT_STREAM_FORMAT,
+    BROTLIG_ERROR_GENERIC
+} BROTLIG_ERROR;
+
+/* Replaces: uint32_t BrotliG::DecompressedSize(uint8_t* src)
+ *   inc/BrotligDecoder.h:32, src/BrotligDecoder.cpp:35-39.
+ * `src` is a HOST pointer to at least the 8-byte stream header.  No validation, like the
+ * reference: NumPages * PageSize - (LastPageSize ? PageSize - LastPageSize : 0). */
+uint32_t DecompressedSize(uint8_t* src);
+
+/* Replaces: BROTLIG_ERROR DecodeGPU(bool useWarpDevice, uint32_t input_size, const uint8_t* input,
+ *                                   uint32_t* output_size, uint8_t* output, double& time)
+ *   sample/BrotligGPUDecoder.h:24, sample/BrotligGPUDecoder.cpp:260-748.
+ * Host pointers in and out.  *output_size must hold the capacity of `output` on entry (for a
+ * preconditioned stream: exactly the texture size, as src/BrotligDecoder.cpp:478 requires) and
+ * receives the decompressed size.  *time_ms (may be NULL) receives the kernel-only time in
+ * milliseconds, measured with HIP events around the decode kernels, mirroring the reference's
+ * timestamp pair around Dispatch (BrotligGPUDecoder.cpp:673-675).  `useWarpDevice` is ignored.
+ * Errors: BROTLIG_ERROR_CORRUPT_STREAM (magic), BROTLIG_ERROR_INCORRECT_STREAM_FORMAT (id != 5)
+ * as src/BrotligDecoder.cpp:437-446; BROTLIG_ERROR_GENERIC for device errors (the reference
+ * throws std::exception there) and for pages that fail a bounds check. */
+BROTLIG_ERROR DecodeGPU(int useWarpDevice, uint32_t input_size, const uint8_t* input,
+                        uint32_t* output_size, uint8_t* output, double* time_ms);
+
+/* ---- device-pointer batch interface -------------------------------------------------------
+ * Replaces the kernel-level contract of the reference shader: three buffers (input = whole
+ * streams back to back, meta = work queue, output) and one dispatch that decodes up to 4096
+ * streams (src/decoder/BrotliGCompute.hlsl:93-95,:1757-1881;
+ * inc/common/BrotligConstants.h:126-129).  Everything is asynchronous on `hip_stream`. */
+typedef struct BrotligStreamDesc {
+    uint64_t in_offset;     /* byte offset of the stream's header in d_in; multiple of 4 */
+    uint64_t out_offset;    /* byte offset of its decompressed bytes in d_out; multiple of 16 */
+} BrotligStreamDesc;
+
+/* Bytes of device workspace needed for `num_streams` streams (the reference's `meta` buffer). */
+size_t BrotligDecodeWorkspaceSize(uint32_t num_streams);
+
+/* Enqueue the decode of `num_streams` streams.
+ *   d_in / in_bytes       device buffer holding the streams; must stay readable 8 bytes past
+ *                         in_bytes only in the sense that reads beyond in_bytes are suppressed
+ *   d_out / out_bytes     device buffer receiving the decompressed bytes
+ *   d_streams             DEVICE array of num_streams descriptors
+ *   d_workspace           device memory, BrotligDecodeWorkspaceSize(num_streams) bytes
+ *   d_scratch             device memory of out_bytes bytes, needed only if a stream is
+ *                         preconditioned (conditioned-space staging); may be NULL otherwise
+ *   hip_stream            hipStream_t (NULL = default stream)
+ * Returns BROTLIG_OK when the launches were enqueued.  Stream/page level failures are
+ * reported by BrotligDecodeBatchStatus. */
+BROTLIG_ERROR BrotligDecodeBatchDevice(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
+                                       const BrotligStreamDesc* d_streams, uint32_t num_streams,
+                                       void* d_workspace, size_t workspace_bytes, void* d_scratch,
+                                       void* hip_stream);
+
+/* Waits for `hip_stream` and returns the status of the last batch that used `d_workspace`:
+ * BROTLIG_OK, BROTLIG_ERROR_CORRUPT_STREAM (a header failed the magic/id check) or
+ * BROTLIG_ERROR_GENERIC (a page failed a bounds check). */
+BROTLIG_ERROR BrotligDecodeBatchStatus(const void* d_workspace, void* hip_stream);
+
+/* Benchmark helper: runs the batch `warmup` + `steps` times on `hip_stream` and reports
+ *   *total_ms        wall time of the `steps` timed passes (HIP events on hip_stream)
+ *   *decode_kernel_ms average duration of the page-decode kernel alone over the timed passes
+ * (the reference's own timing convention is kernel-only: BrotligGPUDecoder.cpp:729-746). */
+BROTLIG_ERROR BrotligDecodeBatchTimed(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
+                                      const BrotligStreamDesc* d_streams, uint32_t num_streams,
+                                      void* d_workspace, size_t workspace_bytes, void* d_scratch,
+                                      void* hip_stream, uint32_t warmup, uint32_t steps,
+                                      double* total_ms, double* decode_kernel_ms);
+
+/* Device self-test of the wave primitives the kernels rely on (DPP scan vs shuffle scan,
+ * half-wave ballot / shuffle / max).  Returns BROTLIG_OK when they agree. */
+BROTLIG_ERROR BrotligDeviceSelfTest(void);
+
+/* Static properties, for reports: LDS bytes per workgroup, workgroups launched. */
+uint32_t BrotligKernelLdsBytes(void);
+uint32_t BrotligKernelGridSize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

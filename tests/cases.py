@@ -1,0 +1,62 @@
+"""Seeded decode cases shared by the oracle, simulator and GPU tests.  Each case is
+(name, data-thunk, encoder kwargs); preconditioned cases carry a `precondition` dict."""
+import numpy as np
+
+from brotli_g_sdk_amd import datagen as D
+from brotli_g_sdk_amd import encoder as E
+
+N = 2 * 65536 + 4321          # two full pages and a short last page
+
+
+def plain_cases():
+    return [
+        ("random_stored", lambda: D.random_bytes(65536, 0), {}),                      # BASELINE config 1
+        ("zeros", lambda: np.zeros(70000, np.uint8), {}),
+        ("one_byte", lambda: np.frombuffer(b"a", dtype=np.uint8), {}),
+        ("short_text", lambda: np.frombuffer(b"abcabcabcabcabcabcabcabcabcabc" * 7, dtype=np.uint8), {}),
+        ("runs", lambda: D.runs(N, 1), {}),
+        ("text", lambda: D.text(N, 2), {}),
+        ("records", lambda: D.records(N, 3), {}),
+        ("samples16", lambda: D.samples16(N, 4), {}),
+        ("mixed", lambda: D.mixed(6 * 65536, 5), {}),
+        ("text_npostfix1", lambda: D.text(N, 2), dict(npostfix=1, ndirect_m=3)),
+        ("records_npostfix2", lambda: D.records(N, 6), dict(npostfix=2, ndirect_m=7)),
+        ("records_npostfix3", lambda: D.records(N, 7), dict(npostfix=3, ndirect_m=15)),
+        ("text_no_rle", lambda: D.text(N, 8), dict(flags=E.NO_CODELEN_RLE)),
+        ("records_no_ring", lambda: D.records(N, 9), dict(flags=E.NO_RING_CODES)),
+        ("text_greedy", lambda: D.text(N, 10), dict(flags=E.NO_LAZY)),
+        ("text_literals_only", lambda: D.text(N, 11), dict(flags=E.LITERALS_ONLY)),
+        ("runs_complex_tables", lambda: D.runs(N, 12), dict(flags=E.FORCE_COMPLEX_TABLES)),
+        ("all_stored", lambda: D.text(N, 13), dict(flags=E.FORCE_STORED)),
+        ("text_32k_pages", lambda: D.text(N, 14), dict(page_size=32768)),
+        ("mixed_128k_pages", lambda: D.mixed(3 * 65536 + 77, 15), dict(page_size=131072)),
+        ("skewed_long_codes", lambda: skewed(N, 16), {}),
+        ("long_matches", lambda: np.tile(D.random_bytes(5000, 17), 40)[:N], {}),
+        ("period_1_2_3", lambda: np.concatenate([np.full(30000, 7, np.uint8), np.tile(np.array([1, 2], np.uint8), 20000),
+                                                 np.tile(np.array([9, 8, 7], np.uint8), 15000)]), {}),
+    ]
+
+
+def skewed(n, seed):
+    """Geometric byte distribution: drives literal code lengths up to the 15-bit limit."""
+    rng = np.random.default_rng(seed)
+    return np.minimum(rng.geometric(0.35, n) - 1, 255).astype(np.uint8)
+
+
+def precon_cases():
+    out = []
+    for name, fmt, w, h, mips, swz, delta, aligned, pitch in [
+        ("bc1_swz_delta", 1, 128, 128, 1, 1, 1, 0, 0),
+        ("bc2_mips4", 2, 32, 32, 4, 1, 1, 0, 0),
+        ("bc3_odd", 3, 64, 50, 1, 1, 1, 0, 0),
+        ("bc4_noswz", 4, 256, 128, 1, 0, 1, 0, 0),
+        ("bc5_odd_mips3", 5, 65, 33, 3, 1, 1, 0, 0),
+        ("bc3_aligned_nodelta", 3, 64, 64, 2, 1, 0, 1, 0),
+        ("bc3_mips6_aligned", 3, 37, 21, 6, 1, 1, 1, 0),
+        ("bc5_pitch_pad", 5, 33, 17, 1, 1, 1, 0, 33 * 16 + 7),
+    ]:
+        pre = dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=swz, delta=delta,
+                   pitch_d3d12_aligned=aligned, pitch_bytes=pitch)
+        out.append((name, (lambda f=fmt, w=w, h=h, m=mips, a=aligned, p=pitch, s=len(out):
+                           D.bc_texture(f, w, h, seed=100 + s, num_mips=m, aligned=bool(a), pitch_bytes=p)), pre))
+    return out

@@ -1,0 +1,63 @@
+// TEST INFRASTRUCTURE: CPU-simulator implementation of the wave:: primitives declared by
+// brotli_g_sdk_amd/csrc/brotlig_wave_ops.h (same names, same semantics).  Selected by putting
+// tests/sim in front of the include path when building tests/sim/sim_decode.cpp.
+#pragma once
+#include "sim_runtime.h"
+
+namespace wave {
+
+inline uint32_t lane_id() { return sim::lane_now() & 63u; }
+
+#define SIM_SITE int site = __builtin_LINE()
+
+inline uint64_t ballot64(bool p, SIM_SITE)
+{
+    const int s = sim::collective_enter(p ? 1 : 0, 0, site);
+    uint64_t m = 0;
+    for (int l = 0; l < sim::kLanes; ++l) if (!sim::g_wave.fiber[l].done && sim::g_wave.in_a[s][l]) m |= 1ull << l;
+    return m;
+}
+inline bool any(bool p, SIM_SITE) { return ballot64(p, site) != 0; }
+inline uint32_t bcast(uint32_t v, uint32_t src, SIM_SITE)
+{
+    const int s = sim::collective_enter(v, 0, site);
+    return (uint32_t)sim::g_wave.in_a[s][src & 63u];
+}
+inline uint32_t half_ballot(bool p, SIM_SITE) { return (uint32_t)(ballot64(p, site) >> (lane_id() & 32u)); }
+inline uint32_t half_shfl(uint32_t v, uint32_t src, SIM_SITE)
+{
+    const int s = sim::collective_enter(v, 0, site);
+    return (uint32_t)sim::g_wave.in_a[s][(lane_id() & 32u) | (src & 31u)];
+}
+inline uint32_t half_scan_incl(uint32_t v, SIM_SITE)
+{
+    const int s = sim::collective_enter(v, 0, site);
+    const uint32_t me = lane_id(), base = me & 32u;
+    uint32_t acc = 0;
+    for (uint32_t l = base; l <= me; ++l) acc += (uint32_t)sim::g_wave.in_a[s][l];
+    return acc;
+}
+inline uint32_t half_scan_incl_ref(uint32_t v, SIM_SITE) { return half_scan_incl(v, site); }
+inline uint32_t half_sum(uint32_t v, SIM_SITE)
+{
+    const int s = sim::collective_enter(v, 0, site);
+    const uint32_t base = lane_id() & 32u;
+    uint32_t acc = 0;
+    for (uint32_t l = base; l < base + 32u; ++l) acc += (uint32_t)sim::g_wave.in_a[s][l];
+    return acc;
+}
+inline uint32_t half_max(uint32_t v, SIM_SITE)
+{
+    const int s = sim::collective_enter(v, 0, site);
+    const uint32_t base = lane_id() & 32u;
+    uint32_t acc = 0;
+    for (uint32_t l = base; l < base + 32u; ++l) { const uint32_t x = (uint32_t)sim::g_wave.in_a[s][l]; acc = x > acc ? x : acc; }
+    return acc;
+}
+inline void sync(SIM_SITE) { sim::collective_enter(0, 0, site); }
+inline void global_fence(SIM_SITE) { sim::collective_enter(0, 0, site); }
+
+#undef SIM_SITE
+}  // namespace wave
+
+inline void __syncthreads() { wave::sync(); }

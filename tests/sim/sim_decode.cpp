@@ -1,0 +1,38 @@
+// TEST INFRASTRUCTURE: runs the HIP decode kernels (brotli_g_sdk_amd/csrc/brotlig_kernels.h) on
+// the CPU simulator.  Built as a shared library and driven from tests/test_sim_decode.py.
+#include <vector>
+
+#include <brotlig_wave_ops.h>
+
+#include "brotlig_kernels.h"
+
+using namespace brotlig;
+
+static void prepare_body(void* p) { brotlig_prepare_kernel(*(DecodeArgs*)p); }
+static void decode_body(void* p) { brotlig_decode_kernel(*(DecodeArgs*)p); }
+static void decond_body(void* p) { brotlig_decondition_kernel(*(DecodeArgs*)p); }
+static void selftest_body(void* p) { brotlig_selftest_kernel((uint32_t*)p); }
+
+extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* out, uint64_t out_bytes,
+                                uint8_t* scratch, const uint64_t* in_offsets, const uint64_t* out_offsets,
+                                uint32_t num_streams, uint32_t grid, uint32_t* status_out)
+{
+    std::vector<StreamDesc> sd(num_streams);
+    for (uint32_t i = 0; i < num_streams; ++i) { sd[i].in_offset = in_offsets[i]; sd[i].out_offset = out_offsets[i]; }
+    std::vector<uint32_t> page_base(num_streams + 1, 0);
+    uint32_t counter = 0;
+    uint32_t status_words[4] = {0, 0, 0, 0};
+    std::vector<DcTable> dc(num_streams);
+    DecodeArgs a{};
+    a.in = in; a.in_bytes = in_bytes; a.out = out; a.out_bytes = out_bytes; a.scratch = scratch;
+    a.streams = sd.data(); a.num_streams = num_streams;
+    a.page_base = page_base.data(); a.work_counter = &counter; a.status = status_words; a.dc = dc.data();
+    sim::run_grid(1, prepare_body, &a);
+    sim::run_grid(grid ? grid : 4, decode_body, &a);
+    sim::run_grid(3, decond_body, &a);
+    *status_out = status_words[0];
+    return 0;
+}
+
+extern "C" void sim_selftest(uint32_t* out) { sim::run_grid(1, selftest_body, out); }
+extern "C" uint64_t sim_collectives() { return sim::g_wave.n_collectives; }

@@ -1,0 +1,95 @@
+// sim_runtime.h -- TEST INFRASTRUCTURE: a tiny CPU stand-in for the HIP execution model so the
+// kernel source in brotli_g_sdk_amd/csrc/brotlig_kernels.h can be executed and debugged on a box
+// without a GPU.  One workgroup (= one wave64) runs at a time; each lane is a fiber; every
+// cross-lane primitive in tests/sim/brotlig_wave_ops.h is a rendezvous of all live lanes that also
+// checks that every lane arrived from the same call site (the kernel's wave-uniformity rule).
+// Nothing here is part of the product, and the product never includes this file.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define __device__
+#define __global__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+namespace sim {
+
+constexpr int kLanes = 64;
+struct Dim3 { uint32_t x, y, z; };
+
+struct Fiber {
+    void* sp;
+    void* stack;
+    bool  done;
+    // rendezvous state
+    uint64_t gen_seen;
+};
+
+struct WaveState {
+    Fiber    fiber[kLanes];
+    void*    sched_sp;
+    int      cur;                 // running lane
+    uint32_t block;               // blockIdx.x
+    uint32_t grid;
+    void   (*body)(void*);
+    void*    arg;
+    // collective
+    uint64_t gen;                 // completed collectives
+    uint64_t in_a[2][kLanes], in_b[2][kLanes];
+    int      site[kLanes];
+    bool     waiting[kLanes];
+    uint64_t n_collectives;
+};
+
+extern WaveState g_wave;
+
+extern "C" void sim_switch(void** from_sp, void* to_sp);
+
+inline void yield_to_scheduler() { sim_switch(&g_wave.fiber[g_wave.cur].sp, g_wave.sched_sp); }
+
+// Deposit operands, wait until every live lane has done so, return the parity slot to read.
+inline int collective_enter(uint64_t a, uint64_t b, int site)
+{
+    WaveState& w = g_wave;
+    const int lane = w.cur;
+    const int slot = (int)(w.gen & 1);
+    const uint64_t my_gen = w.gen;
+    w.in_a[slot][lane] = a; w.in_b[slot][lane] = b;
+    w.site[lane] = site; w.waiting[lane] = true;
+    while (w.gen == my_gen) yield_to_scheduler();
+    return slot;
+}
+
+void run_grid(uint32_t grid, void (*body)(void*), void* arg);
+
+inline uint32_t lane_now() { return (uint32_t)g_wave.cur; }
+
+}  // namespace sim
+
+// ---- HIP built-ins used by the kernels --------------------------------------------------------
+struct SimThreadIdx { uint32_t y = 0, z = 0; struct X { operator uint32_t() const { return sim::lane_now(); } } x; };
+struct SimBlockIdx { uint32_t y = 0, z = 0; struct X { operator uint32_t() const { return sim::g_wave.block; } } x; };
+struct SimGridDim { uint32_t y = 1, z = 1; struct X { operator uint32_t() const { return sim::g_wave.grid; } } x; };
+struct SimBlockDim { uint32_t y = 1, z = 1; uint32_t x = sim::kLanes; };
+static const SimBlockDim blockDim;
+static const SimThreadIdx threadIdx;
+static const SimBlockIdx blockIdx;
+static const SimGridDim gridDim;
+
+inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+inline int __ffs(int x) { return __builtin_ffs(x); }
+inline uint32_t __brev(uint32_t x)
+{
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
+inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }

@@ -1,0 +1,75 @@
+"""N > 1 path on CPU: two gloo ranks shard a list of streams the way bench.py shards work across
+GPUs (independent streams per rank, no data-path collective), decode their shard with the oracle
+standing in for the device, and the gathered digests must equal the single-process result."""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from brotli_g_sdk_amd import datagen as D, encoder as E, shard
+    from helpers import oracle_decode
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_total = 6
+    mine = shard.stream_indices(n_total, world, rank)
+    digests = torch.zeros(n_total, 32, dtype=torch.uint8)
+    nbytes = 0
+    for k in mine:
+        data = D.mixed(2 * 65536 + 17 * k, 200 + k)
+        rc, out = oracle_decode(E.encode(data))
+        assert rc == 0 and np.array_equal(out, data)
+        digests[k] = torch.frombuffer(bytearray(hashlib.sha256(out.tobytes()).digest()), dtype=torch.uint8)
+        nbytes += len(out)
+    ms = shard.max_over_ranks(10.0 + rank)                 # bench.py's timing reduction
+    total = shard.sum_over_ranks(nbytes)
+    dist.all_reduce(digests, op=dist.ReduceOp.SUM)         # test-side gather only; disjoint rows
+    if rank == 0:
+        q.put((ms, total, digests.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_matches_single_process():
+    from brotli_g_sdk_amd import datagen as D, shard
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ms, total, blob = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ms == 11.0
+    expect = b"".join(hashlib.sha256(D.mixed(2 * 65536 + 17 * k, 200 + k).tobytes()).digest() for k in range(6))
+    assert blob == expect
+    assert total == sum(2 * 65536 + 17 * k for k in range(6))
+    # shards are a disjoint cover
+    cover = sorted(i for r in range(world) for i in shard.stream_indices(6, world, r))
+    assert cover == list(range(6))
+
+
+def test_shard_is_contiguous_and_balanced():
+    from brotli_g_sdk_amd import shard
+    for n in (1, 7, 16, 128):
+        for world in (1, 2, 4, 8):
+            parts = [shard.stream_indices(n, world, r) for r in range(world)]
+            flat = [i for p in parts for i in p]
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
