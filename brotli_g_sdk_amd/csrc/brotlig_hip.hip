@@ -164,8 +164,8 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
     const uint64_t out_alloc = (((uint64_t)si.num_pages * si.page_size) + 15u) & ~15ull;
     DevBuf d_in, d_out, d_scratch, d_ws, d_desc;
     HIP_OK(hipMalloc(&d_in.p, in_alloc + 64));
-    HIP_OK(hipMalloc(&d_out.p, out_alloc));
-    if (si.preconditioned) HIP_OK(hipMalloc(&d_scratch.p, out_alloc));
+    HIP_OK(hipMalloc(&d_out.p, out_alloc + 64));                        // copies read up to 7 bytes past a page
+    if (si.preconditioned) HIP_OK(hipMalloc(&d_scratch.p, out_alloc + 64));
     HIP_OK(hipMalloc(&d_ws.p, workspace_bytes(1)));
     HIP_OK(hipMalloc(&d_desc.p, sizeof(BrotligStreamDesc)));
     const BrotligStreamDesc desc{0, 0};

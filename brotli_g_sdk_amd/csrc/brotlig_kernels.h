@@ -161,6 +161,42 @@ __device__ __forceinline__ uint32_t ctz_u32(uint32_t x) { return (uint32_t)__ffs
 __device__ __forceinline__ uint32_t msb_u32(uint32_t x) { return 31u - (uint32_t)__clz((int)x); }     // x != 0
 __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
 
+// Unaligned 8-byte access (gfx950 global memory takes any byte address; hipcc emits dwordx2).
+__device__ __forceinline__ uint64_t load_u64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+// Store the low n (1..8) bytes of v at p.
+__device__ __forceinline__ void store_bytes(uint8_t* p, uint64_t v, uint32_t n)
+{
+    if (n >= 8u) { __builtin_memcpy(p, &v, 8); return; }
+    if (n & 4u) { const uint32_t w = (uint32_t)v; __builtin_memcpy(p, &w, 4); p += 4; v >>= 32; }
+    if (n & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); p += 2; v >>= 16; }
+    if (n & 1u) *p = (uint8_t)v;
+}
+// Eight bytes of an LZ77 copy's source, starting at offset r (< d) of its period: byte k is
+// s[(r + k) mod d].  For d >= copy length this is a plain read; for overlapping copies it replays
+// the first d bytes, so no byte written by the copy itself is ever read back
+// (out[t + j] = out[t - d + (j mod d)], PageDecoder.cpp:219-232 / BrotliGCompute.hlsl:1414-1418).
+__device__ __forceinline__ uint64_t copy_source8(const uint8_t* s, uint32_t d, uint32_t r)
+{
+    if (r + 8u <= d) return load_u64u(s + r);
+    if (d >= 8u) {
+        const uint32_t n = d - r;                                   // 1..7 bytes before the period wraps
+        const uint64_t lo = load_u64u(s + r), hi = load_u64u(s);
+        return (lo & ((1ull << (8u * n)) - 1ull)) | (hi << (8u * n));
+    }
+    const uint64_t p = load_u64u(s);
+    uint64_t v = 0;
+    uint32_t idx = r;
+    for (uint32_t k = 0; k < 8u; ++k) { v |= ((p >> (8u * idx)) & 0xFFull) << (8u * k); if (++idx == d) idx = 0; }
+    return v;
+}
+// r <- (r + step) mod d, for r < d
+__device__ __forceinline__ uint32_t advance_mod(uint32_t r, uint32_t step, uint32_t d)
+{
+    r += step;
+    if (r >= d) r = d >= step ? r - d : r % d;
+    return r;
+}
+
 // One prefix-code table: which LDS arrays it lives in.
 struct TableRef {
     uint16_t* lut; uint16_t* sorted; uint16_t* limit; uint16_t* first; uint16_t* offs;
@@ -561,22 +597,41 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             const bool ready = mine && src_end <= first_dst;
             const uint32_t ready_mask = wave::half_ballot(ready);
             uint32_t long_mask = wave::half_ballot(ready && copy > kShortCopy);
-            if (ready && copy <= kShortCopy) {                          // one lane per command
+            if (ready && copy <= kShortCopy) {                          // one lane per command, <= 4 chunks of 8 bytes
                 uint8_t* d = job.out + copy_dst;
                 const uint8_t* s = d - dist;
+                uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
                 uint32_t r = 0;
-                for (uint32_t i = 0; i < copy; ++i) { d[i] = s[r]; if (++r == dist) r = 0; }
+                v0 = copy_source8(s, dist, r);
+                if (copy > 8u) { r = advance_mod(r, 8u, dist); v1 = copy_source8(s, dist, r); }
+                if (copy > 16u) { r = advance_mod(r, 8u, dist); v2 = copy_source8(s, dist, r); }
+                if (copy > 24u) { r = advance_mod(r, 8u, dist); v3 = copy_source8(s, dist, r); }
+                store_bytes(d, v0, copy);
+                if (copy > 8u) store_bytes(d + 8, v1, copy - 8u);
+                if (copy > 16u) store_bytes(d + 16, v2, copy - 16u);
+                if (copy > 24u) store_bytes(d + 24, v3, copy - 24u);
             }
-            while (wave::any(long_mask != 0u)) {                        // all 32 lanes per command
+            while (wave::any(long_mask != 0u)) {                        // all 32 lanes per command, 8 bytes per lane per step
                 const uint32_t k = long_mask ? ctz_u32(long_mask) : 0u;
                 const uint32_t cd = wave::half_shfl(copy_dst, k), dd = wave::half_shfl(dist, k);
                 const uint32_t cl = wave::half_shfl(copy, k);
                 if (long_mask) {
                     uint8_t* d = job.out + cd;
                     const uint8_t* s = d - dd;
-                    uint32_t r = dd > sl ? sl : sl % dd;
-                    const uint32_t step = dd > 32u ? 32u : 32u % dd;
-                    for (uint32_t j = sl; j < cl; j += 32u) { d[j] = s[r]; r += step; if (r >= dd) r -= dd; }
+                    const bool overlap = dd < cl;
+                    uint32_t r = overlap ? (8u * sl) % dd : 8u * sl;
+                    const uint32_t step = overlap ? 256u % dd : 256u;
+                    for (uint32_t j = 8u * sl; j < cl; j += 1024u) {    // up to four chunks in flight per lane
+                        uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                        v0 = copy_source8(s, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u;
+                        if (j + 256u < cl) { v1 = copy_source8(s, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
+                        if (j + 512u < cl) { v2 = copy_source8(s, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
+                        if (j + 768u < cl) { v3 = copy_source8(s, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
+                        store_bytes(d + j, v0, cl - j);
+                        if (j + 256u < cl) store_bytes(d + j + 256u, v1, cl - j - 256u);
+                        if (j + 512u < cl) store_bytes(d + j + 512u, v2, cl - j - 512u);
+                        if (j + 768u < cl) store_bytes(d + j + 768u, v3, cl - j - 768u);
+                    }
                 }
                 long_mask &= long_mask - 1u;
             }

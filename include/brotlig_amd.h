@@ -74,7 +74,9 @@ size_t BrotligDecodeWorkspaceSize(uint32_t num_streams);
 /* Enqueue the decode of `num_streams` streams.
  *   d_in / in_bytes       device buffer holding the streams; must stay readable 8 bytes past
  *                         in_bytes only in the sense that reads beyond in_bytes are suppressed
- *   d_out / out_bytes     device buffer receiving the decompressed bytes
+ *   d_out / out_bytes     device buffer receiving the decompressed bytes; the allocation must
+ *                         extend 8 bytes past out_bytes (wide source reads of the last page;
+ *                         nothing is written there).  Same for d_scratch.
  *   d_streams             DEVICE array of num_streams descriptors
  *   d_workspace           device memory, BrotligDecodeWorkspaceSize(num_streams) bytes
  *   d_scratch             device memory of out_bytes bytes, needed only if a stream is
