@@ -41,6 +41,10 @@ def build_streams(kind, indices, pages_per_stream, distinct):
             data = D.runs(distinct * PAGE, seed + 1)
         elif kind == "text":
             data = D.text(distinct * PAGE, seed)
+        elif kind == "records":
+            data = D.records(distinct * PAGE, seed)
+        elif kind == "samples16":
+            data = D.samples16(distinct * PAGE, seed)
         else:
             raise SystemExit(f"unknown workload {kind}")
         small = E.encode(data)
@@ -91,7 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="mixed", choices=["mixed", "runs", "text"])
+    ap.add_argument("--workload", default="mixed", choices=["mixed", "runs", "text", "records", "samples16"])
     ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--pages-per-stream", type=int, default=4096)
     ap.add_argument("--distinct", type=int, default=256, help="distinct encoded pages per stream (tiled)")

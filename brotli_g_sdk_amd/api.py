@@ -51,6 +51,8 @@ def lib():
         L.BrotligDecodeBatchTimed.restype = ctypes.c_int
         L.BrotligDecodeBatchTimed.argtypes = batch + [ctypes.c_uint32, ctypes.c_uint32,
                                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.BrotligDecodePhaseProfile.restype = ctypes.c_int
+        L.BrotligDecodePhaseProfile.argtypes = batch[:9] + [ctypes.c_void_p, ctypes.c_uint32]
         L.BrotligDeviceSelfTest.restype = ctypes.c_int
         L.BrotligKernelLdsBytes.restype = ctypes.c_uint32
         L.BrotligKernelGridSize.restype = ctypes.c_uint32
@@ -158,6 +160,19 @@ class BatchDecoder:
             if rc != BROTLIG_OK:
                 raise BrotligError(rc, "BrotligDecodeBatchStatus")
             return total.value, kern.value
+
+    PHASES = ("setup", "tables", "commands", "ring", "positions", "literals", "copy_fence", "copy_levels",
+              "delta", "total", "rounds", "levels", "lv_short", "lv_bytes", "lv_long", "slow_round")
+
+    def phase_profile(self):
+        """Per-phase shader-clock sums from the phase-timer twin of the decode kernel (diagnostics)."""
+        with self.torch.cuda.device(self.device):
+            self.torch.cuda.synchronize()
+            out = np.zeros(len(self.PHASES), dtype=np.uint64)
+            rc = lib().BrotligDecodePhaseProfile(*self._args(None)[:9], out.ctypes.data, len(out))
+            if rc != BROTLIG_OK:
+                raise BrotligError(rc, "BrotligDecodePhaseProfile")
+            return dict(zip(self.PHASES, (int(x) for x in out)))
 
     def output(self, i):
         """Decompressed bytes of stream i as a host uint8 array."""

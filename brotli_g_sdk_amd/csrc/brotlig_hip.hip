@@ -192,9 +192,9 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
 extern "C" BROTLIG_ERROR BrotligDeviceSelfTest(void)
 {
     DevBuf d;
-    HIP_OK(hipMalloc(&d.p, 384 * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&d.p, 448 * sizeof(uint32_t)));
     hipLaunchKernelGGL(brotlig_selftest_kernel, dim3(1), dim3(64), 0, nullptr, static_cast<uint32_t*>(d.p));
-    uint32_t h[384];
+    uint32_t h[448];
     HIP_OK(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
     const uint32_t* v = h + 320;
     for (uint32_t lane = 0; lane < 64; ++lane) {
@@ -206,11 +206,36 @@ extern "C" BROTLIG_ERROR BrotligDeviceSelfTest(void)
             if (v[l] & 1u) bal |= 1u << (l - base);
         }
         if (h[lane] != sum || h[64 + lane] != sum || h[128 + lane] != bal ||
-            h[192 + lane] != v[base | ((lane * 7u + 3u) & 31u)] || h[256 + lane] != mx) {
+            h[192 + lane] != v[base | ((lane * 7u + 3u) & 31u)] || h[256 + lane] != mx ||
+            h[384 + lane] != v[base | (base ? 5u : 29u)]) {
             fprintf(stderr, "brotlig_hip: wave primitive self-test failed at lane %u\n", lane);
             return BROTLIG_ERROR_GENERIC;
         }
     }
+    return BROTLIG_OK;
+}
+
+extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
+                                                   const BrotligStreamDesc* d_streams, uint32_t num_streams,
+                                                   void* d_workspace, size_t ws_bytes, void* d_scratch,
+                                                   uint64_t* cycles_out, uint32_t n_out)
+{
+    if (!d_in || !d_out || !d_streams || !d_workspace || num_streams == 0 || !cycles_out) return BROTLIG_ERROR_GENERIC;
+    if (ws_bytes < workspace_bytes(num_streams)) return BROTLIG_ERROR_GENERIC;
+    int grid = 0;
+    if (BROTLIG_ERROR e = grid_size(&grid)) return e;
+    DevBuf prof;
+    HIP_OK(hipMalloc(&prof.p, kNumPhases * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(prof.p, 0, kNumPhases * sizeof(unsigned long long)));
+    DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, d_scratch);
+    a.prof = static_cast<unsigned long long*>(prof.p);
+    HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), nullptr));
+    hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(1), dim3(64), 0, nullptr, a);
+    hipLaunchKernelGGL(brotlig_decode_kernel_timed, dim3(grid), dim3(64), 0, nullptr, a);
+    HIP_OK(hipDeviceSynchronize());
+    unsigned long long h[kNumPhases];
+    HIP_OK(hipMemcpy(h, prof.p, sizeof h, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_out; ++i) cycles_out[i] = i < (uint32_t)kNumPhases ? h[i] : 0;
     return BROTLIG_OK;
 }
 

@@ -59,14 +59,45 @@ struct DecodeArgs {
     uint32_t* work_counter; // [1] next global page index
     uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams
     DcTable*  dc;           // [num_streams]
+    unsigned long long* prof;   // [kNumPhases] cycle sums, only written by the phase-timer instantiation
+};
+
+// Phase timers (diagnostics build of the kernel only).
+enum : int { kPhSetup, kPhTables, kPhCommands, kPhRing, kPhPositions, kPhLiterals, kPhCopyFence, kPhCopyLevels,
+             kPhDelta, kPhTotal, kPhRounds, kPhLevels, kPhLvShort, kPhLvBytes, kPhLvLong, kPhSlow, kNumPhases };
+template <bool kOn> struct PhaseClock;
+template <> struct PhaseClock<false> {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void lap(int) {}
+    __device__ __forceinline__ void count(int, uint32_t) {}
+    __device__ __forceinline__ void flush(unsigned long long*, uint32_t) {}
+};
+template <> struct PhaseClock<true> {
+    unsigned long long t0, last, acc[kNumPhases];
+    __device__ __forceinline__ void start() { for (int i = 0; i < kNumPhases; ++i) acc[i] = 0; t0 = last = wave::clock(); }
+    __device__ __forceinline__ void lap(int ph) { const unsigned long long t = wave::clock(); acc[ph] += t - last; last = t; }
+    __device__ __forceinline__ void count(int ph, uint32_t n) { acc[ph] += n; }
+    __device__ __forceinline__ void flush(unsigned long long* out, uint32_t lane)
+    {
+        acc[kPhTotal] = wave::clock() - t0;
+        if (lane == 0u && out) for (int i = 0; i < kNumPhases; ++i) atomicAdd(out + i, acc[i]);
+    }
 };
 
 // ---- tunables ---------------------------------------------------------------------------
 constexpr int kLutBitsIcp = 10;
 constexpr int kLutBitsDist = 9;
-constexpr int kLutBitsLit = 10;
+constexpr int kLutBitsLit = 9;
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index
 constexpr uint32_t kShortCopy = 32;         // copies up to this length run one-lane-per-command
+// Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
+// output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
+// between copies); bytes older than the window are read back from global memory.  The window is
+// flushed to global memory in aligned 16-byte stores when it slides.
+constexpr uint32_t kWin = 2048;
+constexpr uint32_t kHist = 1024;            // history kept across a slide (>= kWin / 2: see slide_window)
+constexpr uint32_t kRoundMax = kWin - kHist;
+constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
 
 // insert / copy length codes: base | extra_bits << 16   (RFC 7932 section 5; the reference carries
 // them as sBrotligCmdLut, inc/common/BrotligCommandLut.h:41-747, and the shader regenerates them
@@ -99,8 +130,15 @@ struct __attribute__((aligned(16))) PageLds {
     uint16_t offs[3][16];       // index of the first symbol of the length in sorted_*
     uint32_t round_ins_incl[32];    // per round: inclusive prefix of insert lengths
     uint32_t round_copy_excl[32];   // per round: exclusive prefix of copy lengths
-    uint8_t  lens[kIcpAlphabet];    // code lengths of the table being built
+    uint32_t start_bits[kRoundMax / 32];    // per round: bit p set <=> a command starts at round byte p
+    uint32_t start_cum[kRoundMax / 32];     // per round: command starts in earlier words of start_bits
+    uint32_t lit_bits[kRoundMax / 32 + 2];  // per round: bit j set <=> decoded literal j is the first of a literal run
+    uint32_t lit_shift[32];                 // per round: copy bytes preceding the r-th literal run
+    uint64_t stage[kStageBytes / 8];        // per round: source bytes of far copies (older than the window)
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
+    uint8_t  sink[64];              // write target of inactive lanes in branch-free copy loops
+    uint8_t  win[kWin + 48] __attribute__((aligned(16)));   // output window; doubles as the code-length
+                                                             // scratch (728 B) while tables are built
 };
 
 struct __attribute__((aligned(16))) WaveLds {
@@ -171,15 +209,57 @@ __device__ __forceinline__ void store_bytes(uint8_t* p, uint64_t v, uint32_t n)
     if (n & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); p += 2; v >>= 16; }
     if (n & 1u) *p = (uint8_t)v;
 }
+// Where a page's bytes are while it is being decoded: positions >= valid_from are in the LDS window
+// (win[pos - win_base]); everything below `flushed` is in global memory (out[pos]).
+struct OutView {
+    uint8_t* out;
+    uint8_t* win;
+    uint32_t win_base;      // page position of win[0]; multiple of 16
+    uint32_t valid_from;    // window holds [valid_from, frontier)
+    bool     use_win;       // this round is assembled in the window (else straight in global memory)
+
+    __device__ __forceinline__ uint64_t read8(uint32_t pos) const
+    {
+        if (!use_win || pos + 8u <= valid_from) return load_u64u(out + pos);
+        if (pos >= valid_from) return load_u64u(win + (pos - win_base));
+        const uint32_t n = valid_from - pos;                        // 1..7 bytes still only in global memory
+        const uint64_t lo = load_u64u(out + pos), hi = load_u64u(win + (valid_from - win_base));
+        return (lo & ((1ull << (8u * n)) - 1ull)) | (hi << (8u * n));
+    }
+    __device__ __forceinline__ void write(uint32_t pos, uint64_t v, uint32_t n) const
+    {
+        store_bytes(use_win ? win + (pos - win_base) : out + pos, v, n);
+    }
+    __device__ __forceinline__ void put(uint32_t pos, uint32_t byte) const
+    {
+        if (use_win) win[pos - win_base] = (uint8_t)byte; else out[pos] = (uint8_t)byte;
+    }
+};
+
 // Eight bytes of an LZ77 copy's source, starting at offset r (< d) of its period: byte k is
-// s[(r + k) mod d].  For d >= copy length this is a plain read; for overlapping copies it replays
-// the first d bytes, so no byte written by the copy itself is ever read back
+// page[sp + (r + k) mod d].  For d >= copy length this is a plain read; for overlapping copies it
+// replays the first d bytes, so no byte written by the copy itself is ever read back
 // (out[t + j] = out[t - d + (j mod d)], PageDecoder.cpp:219-232 / BrotliGCompute.hlsl:1414-1418).
-__device__ __forceinline__ uint64_t copy_source8(const uint8_t* s, uint32_t d, uint32_t r)
+__device__ __forceinline__ uint64_t copy_source8(const OutView& o, uint32_t sp, uint32_t d, uint32_t r)
+{
+    if (r + 8u <= d) return o.read8(sp + r);
+    if (d >= 8u) {
+        const uint32_t n = d - r;                                   // 1..7 bytes before the period wraps
+        const uint64_t lo = o.read8(sp + r), hi = o.read8(sp);
+        return (lo & ((1ull << (8u * n)) - 1ull)) | (hi << (8u * n));
+    }
+    const uint64_t p = o.read8(sp);
+    uint64_t v = 0;
+    uint32_t idx = r;
+    for (uint32_t k = 0; k < 8u; ++k) { v |= ((p >> (8u * idx)) & 0xFFull) << (8u * k); if (++idx == d) idx = 0; }
+    return v;
+}
+// Same as copy_source8, for a pattern that lies entirely in LDS at `s`.
+__device__ __forceinline__ uint64_t pattern_source8(const uint8_t* s, uint32_t d, uint32_t r)
 {
     if (r + 8u <= d) return load_u64u(s + r);
     if (d >= 8u) {
-        const uint32_t n = d - r;                                   // 1..7 bytes before the period wraps
+        const uint32_t n = d - r;
         const uint64_t lo = load_u64u(s + r), hi = load_u64u(s);
         return (lo & ((1ull << (8u * n)) - 1ull)) | (hi << (8u * n));
     }
@@ -188,6 +268,24 @@ __device__ __forceinline__ uint64_t copy_source8(const uint8_t* s, uint32_t d, u
     uint32_t idx = r;
     for (uint32_t k = 0; k < 8u; ++k) { v |= ((p >> (8u * idx)) & 0xFFull) << (8u * k); if (++idx == d) idx = 0; }
     return v;
+}
+// Store window bytes [from, to) of the page to global memory: up to 15 head bytes, then aligned
+// 16-byte pieces (one per lane per step), then -- only when `exact` -- the tail bytes.  Without
+// `exact` the range is cut at the last 16-byte boundary.  Returns the new flushed position.
+__device__ __forceinline__ uint32_t flush_window(const OutView& o, uint32_t from, uint32_t to, bool exact, uint32_t sl)
+{
+    const uint32_t end = exact ? to : (to & ~15u);
+    if (end <= from) return from;
+    const uint32_t a = min_u32(end, (from + 15u) & ~15u);
+    for (uint32_t p = from + sl; p < a; p += 32u) o.out[p] = o.win[p - o.win_base];
+    const uint32_t e16 = end & ~15u;
+    for (uint32_t p = a + 16u * sl; p < e16; p += 512u) {
+        uint64_t v[2];
+        __builtin_memcpy(v, o.win + (p - o.win_base), 16);
+        __builtin_memcpy(o.out + p, v, 16);
+    }
+    for (uint32_t p = (e16 > a ? e16 : a) + sl; p < end; p += 32u) o.out[p] = o.win[p - o.win_base];
+    return end;
 }
 // r <- (r + step) mod d, for r < d
 __device__ __forceinline__ uint32_t advance_mod(uint32_t r, uint32_t step, uint32_t d)
@@ -233,7 +331,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
     // -- header: lane 0 of the half reads 6 bits from sub-stream 0
     uint32_t hdr = 0;
     if (live && sl == 0u) hdr = br.read(6);
-    hdr = wave::half_shfl(hdr, 0);
+    hdr = wave::half_bcast(hdr, 0);
     const uint32_t type = hdr & 3u;
     const bool is_trivial = live && type == 0u;
     const bool is_simple = live && type == 1u;
@@ -244,8 +342,8 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
     const uint32_t tree_select = (hdr >> 4) & 1u;
     uint32_t mysym = 0;
     if ((is_trivial || is_simple) && sl < nsym) mysym = br.read(maxbits);
-    const uint32_t s0 = wave::half_shfl(mysym, 0), s1 = wave::half_shfl(mysym, 1);
-    const uint32_t s2 = wave::half_shfl(mysym, 2), s3 = wave::half_shfl(mysym, 3);
+    const uint32_t s0 = wave::half_bcast(mysym, 0), s1 = wave::half_bcast(mysym, 1);
+    const uint32_t s2 = wave::half_bcast(mysym, 2), s3 = wave::half_bcast(mysym, 3);
     // -- complex: code-length code, then RLE-coded code lengths
     if (wave::any(is_complex)) {
         // 18 code-length-code lengths, the k-th from sub-stream k, for symbols in a fixed order
@@ -257,7 +355,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         // canonical code of my code-length symbol: sum over symbols that precede it in (length, symbol) order
         uint32_t cl_code = 0;
         for (uint32_t j = 0; j < 18u; ++j) {
-            const uint32_t lj = wave::half_shfl(cl_len, j), sj = wave::half_shfl(cl_sym, j);
+            const uint32_t lj = wave::half_bcast(cl_len, j), sj = wave::half_bcast(cl_sym, j);
             if (cl_len && lj && (lj < cl_len || (lj == cl_len && sj < cl_sym))) cl_code += 1u << (cl_len - lj);
         }
         // 9-bit LUT: entry = sym << 4 | len, index = next 9 stream bits (LSB-first)
@@ -291,13 +389,13 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
             const uint32_t lit_mask = wave::half_ballot(valid && sym < 16u);
             const uint32_t before = lit_mask & ((1u << sl) - 1u);
             const uint32_t from_lane = wave::half_shfl(sym, before ? msb_u32(before) : 0u);
-            const uint32_t last_lit = wave::half_shfl(sym, lit_mask ? msb_u32(lit_mask) : 0u);
+            const uint32_t last_lit = wave::half_bcast(sym, lit_mask ? msb_u32(lit_mask) : 0u);
             uint32_t value = sym;                                  // literal length
             if (sym == 17u) value = 0u;
             else if (sym == 16u) value = before ? from_lane : prev_len;    // repeat previous *literal* length
             if (valid) {
                 const uint32_t end = min_u32(start + run, A);
-                for (uint32_t s = start; s < end; ++s) L.lens[s] = (uint8_t)value;
+                for (uint32_t s = start; s < end; ++s) L.win[s] = (uint8_t)value;
             }
             produced = min_u32(A, produced + wave::half_sum(valid ? run : 0u));
             if (lit_mask) prev_len = last_lit;
@@ -312,13 +410,13 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         if (is_complex) for (uint32_t l = 0; l < 16u; ++l) cnt[l * 32u + sl] = 0;
         wave::sync();
         if (is_complex)
-            for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = L.lens[s] & 15u; if (l) cnt[l * 32u + sl]++; }
+            for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = L.win[s] & 15u; if (l) cnt[l * 32u + sl]++; }
         wave::sync();
         uint32_t code = 0, off = 0, prev_count = 0;
         for (uint32_t l = 1; l < 16u; ++l) {
             const uint32_t c = is_complex ? cnt[l * 32u + sl] : 0u;
             const uint32_t incl = wave::half_scan_incl(c);
-            const uint32_t total = wave::half_shfl(incl, 31);
+            const uint32_t total = wave::half_bcast(incl, 31);
             if (is_complex) cnt[l * 32u + sl] = (uint16_t)(off + incl - c);
             code = (code + prev_count) << 1;
             if (is_complex && sl == 0u) {
@@ -331,7 +429,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         wave::sync();
         if (is_complex)
             for (uint32_t s = b0; s < b1; ++s) {
-                const uint32_t l = L.lens[s] & 15u;
+                const uint32_t l = L.win[s] & 15u;
                 if (l) { const uint32_t p = cnt[l * 32u + sl]++; t.sorted[min_u32(p, A - 1u)] = (uint16_t)s; }
             }
         wave::sync();
@@ -384,8 +482,11 @@ struct PageJob {
     bool     valid;
 };
 
-__device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t* status)
+template <bool kProf>
+__device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t* status, unsigned long long* prof)
 {
+    PhaseClock<kProf> clk;
+    clk.start();
     const uint32_t lane = wave::lane_id();
     const uint32_t sl = lane & 31u;
     PageLds& L = W.page[lane >> 5];
@@ -430,6 +531,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
         if (live) br.init(job.in, job.in_limit, hdr_bytes + incl - my_len);
     }
 
+    clk.lap(kPhSetup);
     // ---- three prefix codes: ICP, distance, literal (PageDecoder.cpp:125-147)
     const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first[0], L.offs[0], kIcpAlphabet, kLutBitsIcp};
     const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first[1], L.offs[1], kDistAlphabet, kLutBitsDist};
@@ -437,6 +539,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
     build_table(t_icp, L, br, live, sl);
     build_table(t_dist, L, br, live, sl);
     build_table(t_lit, L, br, live, sl);
+    clk.lap(kPhTables);
 
     // ---- rounds (PageDecoder.cpp:174-236; format A.6)
     uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16;             // PageDecoder.cpp:150-153
@@ -445,6 +548,9 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
     uint32_t carry_head = 0;
     uint32_t rounds_left = job.page_size / 64u + 4u;                    // every full round emits >= 64 bytes
     bool bad = false;
+    OutView view{job.out, L.win, 0u, 0u, true};
+    uint32_t flushed = 0;            // page bytes below this are in global memory
+    const bool windowed = live;      // this half decodes a compressed page (and owes a final flush)
 
     while (wave::any(live)) {
         // -- 1. one command per lane
@@ -486,6 +592,8 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             }
         }
 
+        clk.lap(kPhCommands);
+        clk.count(kPhRounds, 1);
         // -- 2. distance ring (PageDecoder.cpp:345-364, :396-403): codes 1..15 are resolved in
         //       command order; explicit distances and code 0 need no serial step
         const bool is_copy = is_cmd && copy > 0u;
@@ -493,12 +601,12 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
         uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
         while (wave::any(pend != 0u)) {
             const uint32_t k = pend ? ctz_u32(pend) : 0u;
-            const uint32_t kd = wave::half_shfl(dcode, k);
+            const uint32_t kd = wave::half_bcast(dcode, k);
             const uint32_t r = kd < 4u ? kd : (kd < 10u ? 0u : 1u);
             uint32_t below = push_mask & ((1u << k) - 1u);
             const uint32_t cnt = (uint32_t)__popc(below);
             for (uint32_t i = 0; i < r && below; ++i) below &= ~(1u << msb_u32(below));
-            const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
+            const uint32_t from = wave::half_bcast(dist, below ? msb_u32(below) : 0u);
             uint32_t val;
             if (r < cnt) val = from;
             else { const uint32_t q = r - cnt; val = q == 0u ? ring0 : q == 1u ? ring1 : q == 2u ? ring2 : ring3; }
@@ -521,8 +629,8 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             if (m) { l1 = msb_u32(m); m &= ~(1u << l1); }
             if (m) { l2 = msb_u32(m); m &= ~(1u << l2); }
             if (m) { l3 = msb_u32(m); }
-            const uint32_t d0 = wave::half_shfl(dist, l0), d1 = wave::half_shfl(dist, l1);
-            const uint32_t d2 = wave::half_shfl(dist, l2), d3 = wave::half_shfl(dist, l3);
+            const uint32_t d0 = wave::half_bcast(dist, l0), d1 = wave::half_bcast(dist, l1);
+            const uint32_t d2 = wave::half_bcast(dist, l2), d3 = wave::half_bcast(dist, l3);
             const uint32_t o0 = ring0, o1 = ring1, o2 = ring2;
             if (cnt >= 4u) { ring0 = d0; ring1 = d1; ring2 = d2; ring3 = d3; }
             else if (cnt == 3u) { ring0 = d0; ring1 = d1; ring2 = d2; ring3 = o0; }
@@ -530,12 +638,13 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             else if (cnt == 1u) { ring0 = d0; ring1 = o0; ring2 = o1; ring3 = o2; }
         }
 
+        clk.lap(kPhRing);
         // -- 3. output positions
         const uint32_t tot = ins + copy;
         const uint32_t incl_tot = wave::half_scan_incl(tot);
         const uint32_t incl_ins = wave::half_scan_incl(ins);
-        const uint32_t round_bytes = wave::half_shfl(incl_tot, 31);
-        const uint32_t litcount = wave::half_shfl(incl_ins, 31);
+        const uint32_t round_bytes = wave::half_bcast(incl_tot, 31);
+        const uint32_t litcount = wave::half_bcast(incl_ins, 31);
         const uint32_t cmd_out = out_pos + incl_tot - tot;              // first literal of my command
         const uint32_t copy_dst = cmd_out + ins;
         if (live) {
@@ -546,10 +655,109 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
 
         L.round_ins_incl[sl] = incl_ins;
         L.round_copy_excl[sl] = (incl_tot - tot) - (incl_ins - ins);
-        wave::sync();
 
+        // -- 3b. output window: a round of at most kRoundMax bytes is assembled in LDS; make room
+        //        for it (flush + slide) first.  Bigger rounds go straight through global memory:
+        //        everything the window holds is flushed, and the window restarts empty after them.
+        const bool fast = live && round_bytes <= kRoundMax;
+        const bool slow = live && !fast;
+        const bool slide = fast && out_pos + round_bytes > view.win_base + kWin;
+        wave::sync();
+        if (wave::any(slide || slow)) {
+            if (slide || slow) flushed = flush_window(view, flushed, out_pos, slow, sl);
+            // keep kHist bytes of history.  kHist >= kWin / 2, so every byte flushed by THIS slide is
+            // still inside the window: reads from global memory only ever touch bytes flushed by an
+            // earlier slide.  The move runs 256 bytes per step (8 per lane), all reads of a step before
+            // its writes; the destination trails the source, so no unread byte is overwritten.
+            const uint32_t nb = slide ? (out_pos - kHist) & ~15u : view.win_base;
+            const uint32_t shift = nb - view.win_base, count = shift ? out_pos - nb : 0u;
+            for (uint32_t i0 = 0; wave::any(i0 < count); i0 += 256u) {
+                const uint32_t i = i0 + 8u * sl;
+                const uint64_t v = i < count ? load_u64u(view.win + shift + i) : 0ull;
+                wave::sync();
+                if (i < count) __builtin_memcpy(view.win + i, &v, 8);
+                wave::sync();
+            }
+            if (slide) {
+                view.win_base = nb;
+                if (view.valid_from < nb) view.valid_from = nb;
+            }
+        }
+        wave::sync();
+        view.use_win = fast;
+
+        // -- 3c. windowed round: per-round lookup structures, and the loads of far copies (sources
+        //        older than the window) issued early so that they fly during the literal decode
+        const uint32_t span0 = out_pos - view.win_base;                 // window index of the round's first byte
+        const uint32_t src_pos = copy_dst - dist;
+        const bool do_copy = ok_cmd && copy > 0u;
+        const bool dist_ok = dist != 0u && dist <= copy_dst;
+        if (do_copy && !dist_ok) bad = true;
+        const bool cp = do_copy && dist_ok;
+        // the first far_len bytes of the copy's source pattern lie below the window and are fetched
+        // from global memory into the staging area; the rest of the pattern is read from the window
+        const uint32_t pattern = min_u32(copy, dist);
+        const uint32_t src_end = src_pos + pattern;
+        const uint32_t far_len = (fast && cp && src_pos < view.valid_from) ? min_u32(pattern, view.valid_from - src_pos) : 0u;
+        const bool far_short = far_len != 0u && far_len <= kShortCopy;
+        const uint32_t stage_len = (far_len + 7u) & ~7u;
+        const uint32_t stage_incl = wave::half_scan_incl(stage_len);
+        const uint32_t stage_off = stage_incl - stage_len;              // 8-byte aligned offset into L.stage
+        uint64_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+        if (far_short) {
+            const uint8_t* s = job.out + src_pos;
+            f0 = load_u64u(s);
+            if (far_len > 8u) f1 = load_u64u(s + 8);
+            if (far_len > 16u) f2 = load_u64u(s + 16);
+            if (far_len > 24u) f3 = load_u64u(s + 24);
+        }
+        // literal runs: command k consumes literals [lit_a, lit_b) of the round; the ones at or past
+        // prev_tail are decoded this round (decoded literal j is consumption index prev_tail + j)
+        const uint32_t lit_a = incl_ins - ins, lit_b = incl_ins;
+        const bool has_run = fast && ok_cmd && lit_b > prev_tail && ins > 0u;
+        const uint32_t run_mask = wave::half_ballot(has_run);
+        if (fast) {
+            L.start_bits[sl] = 0u;
+            L.lit_bits[sl] = 0u;
+            if (sl < 2u) L.lit_bits[32u + sl] = 0u;
+        }
+        wave::sync();
+        if (fast && ok_cmd) {
+            const uint32_t rel = cmd_out - out_pos;
+            atomicOr(&L.start_bits[rel >> 5], 1u << (rel & 31u));
+            if (has_run) {
+                const uint32_t j0 = lit_a > prev_tail ? lit_a - prev_tail : 0u;
+                atomicOr(&L.lit_bits[j0 >> 5], 1u << (j0 & 31u));
+                L.lit_shift[__popc(run_mask & ((1u << sl) - 1u))] = (incl_tot - tot) - lit_a;   // copy bytes before the run
+            }
+        }
+        wave::sync();
+        {
+            const uint32_t w = fast ? L.start_bits[sl] : 0u;
+            const uint32_t cum = wave::half_scan_incl((uint32_t)__popc(w));
+            if (fast) L.start_cum[sl] = cum - (uint32_t)__popc(w);
+        }
+        wave::sync();
+        // exact dependencies of my copy: the commands (before me) whose output overlaps my source
+        uint32_t dep_mask = 0;
+        if (fast && cp && src_end > out_pos) {
+            const uint32_t hi_rel = src_end - 1u - out_pos;
+            const uint32_t hi = L.start_cum[hi_rel >> 5] + (uint32_t)__popc(L.start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
+            uint32_t lo = 0;
+            if (src_pos > out_pos) {
+                const uint32_t lo_rel = src_pos - out_pos;
+                lo = L.start_cum[lo_rel >> 5] + (uint32_t)__popc(L.start_bits[lo_rel >> 5] & (0xFFFFFFFFu >> (31u - (lo_rel & 31u)))) - 1u;
+            }
+            // commands lo .. hi-1 own bytes of [src_pos, src_end); only those before me can be unfinished
+            dep_mask = (hi >= 32u ? 0xFFFFFFFFu : (1u << hi) - 1u) & ~((1u << lo) - 1u) & ((1u << sl) - 1u);
+        }
+
+        clk.lap(kPhPositions);
         // -- 4. literals: literal j of the round comes from sub-stream j mod 32 and is the
-        //       (prev_tail + j)-th literal the round's commands consume (PageDecoder.cpp:196-206)
+        //       (prev_tail + j)-th literal the round's commands consume (PageDecoder.cpp:196-206).
+        //       Each literal goes straight to its place: in a windowed round the owning literal run is
+        //       the number of run starts at or below j (one bitmap word per step of 32 literals); in a
+        //       global-memory round the owner is found by binary search over the insert prefix sums.
         if (live) {
             const uint32_t ac = litcount > prev_tail ? litcount - prev_tail : 0u;
             const uint32_t mult = n ? (ac + n - 1u) / n : 0u;
@@ -562,75 +770,215 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
                 const uint32_t f = sl;
                 uint32_t c = 0;
                 for (uint32_t s = 16; s; s >>= 1) if (L.round_ins_incl[c + s - 1u] <= f) c += s;
-                job.out[out_pos + f + L.round_copy_excl[c]] = L.carry[(carry_head + f) & 63u];
+                view.put(out_pos + f + L.round_copy_excl[c], L.carry[(carry_head + f) & 63u]);
             }
+            uint32_t runs_before = 0;
             for (uint32_t j = sl; j < rlit; j += 32u) {
                 uint32_t ll;
                 br.ensure(15);
                 const uint32_t lit = decode_symbol(t_lit, br, ll);
                 br.consume(ll);
                 const uint32_t f = prev_tail + j;
-                if (f < litcount) {
+                if (f >= litcount) L.carry[(new_head + kept + (f - litcount)) & 63u] = (uint8_t)lit;
+                else if (fast) {
+                    const uint32_t w = L.lit_bits[j >> 5];
+                    const uint32_t run = runs_before + (uint32_t)__popc(w & (0xFFFFFFFFu >> (31u - sl))) - 1u;
+                    L.win[span0 + f + L.lit_shift[run & 31u]] = (uint8_t)lit;
+                    runs_before += (uint32_t)__popc(w);
+                } else {
                     uint32_t c = 0;
                     for (uint32_t s = 16; s; s >>= 1) if (L.round_ins_incl[c + s - 1u] <= f) c += s;
                     job.out[out_pos + f + L.round_copy_excl[c]] = (uint8_t)lit;
-                } else {
-                    L.carry[(new_head + kept + (f - litcount)) & 63u] = (uint8_t)lit;
                 }
             }
             carry_head = new_head;
             prev_tail = rlit + prev_tail - litcount;
         }
 
-        // -- 5. LZ77 copies in dependency levels.  A copy is ready once its source range ends at or
-        //       below the destination of the first unfinished copy; a copy never depends on itself
-        //       because overlapping sources are read modulo the distance.
-        const bool do_copy = ok_cmd && copy > 0u;
-        const bool dist_ok = dist != 0u && dist <= copy_dst;
-        if (do_copy && !dist_ok) bad = true;
-        uint32_t todo = wave::half_ballot(do_copy && dist_ok);
-        const uint32_t src_end = copy_dst - dist + min_u32(copy, dist);
-        wave::global_fence();                                           // this round's literals, earlier rounds' bytes
+        clk.lap(kPhLiterals);
+        // -- 5a. windowed round: far copies into the staging area (aligned 8-byte LDS writes)
+        if (far_short) {
+            uint64_t* st = &L.stage[stage_off >> 3];
+            st[0] = f0;
+            if (far_len > 8u) st[1] = f1;
+            if (far_len > 16u) st[2] = f2;
+            if (far_len > 24u) st[3] = f3;
+        }
+        {
+            uint32_t long_far = wave::half_ballot(far_len > kShortCopy);
+            while (wave::any(long_far != 0u)) {                         // all 32 lanes per command
+                const uint32_t k = long_far ? ctz_u32(long_far) : 0u;
+                const uint32_t sp = wave::half_bcast(src_pos, k), cl = wave::half_bcast(far_len, k);
+                const uint32_t so = wave::half_bcast(stage_off, k);
+                if (long_far) {
+                    for (uint32_t j = 8u * sl; j < cl; j += 1024u) {
+                        uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                        v0 = load_u64u(job.out + sp + j);
+                        if (j + 256u < cl) v1 = load_u64u(job.out + sp + j + 256u);
+                        if (j + 512u < cl) v2 = load_u64u(job.out + sp + j + 512u);
+                        if (j + 768u < cl) v3 = load_u64u(job.out + sp + j + 768u);
+                        L.stage[(so + j) >> 3] = v0;
+                        if (j + 256u < cl) L.stage[(so + j + 256u) >> 3] = v1;
+                        if (j + 512u < cl) L.stage[(so + j + 512u) >> 3] = v2;
+                        if (j + 768u < cl) L.stage[(so + j + 768u) >> 3] = v3;
+                    }
+                }
+                long_far &= long_far - 1u;
+            }
+        }
+        wave::sync();
+        clk.lap(kPhCopyFence);
+        // -- 5b. windowed round: LZ77 copies, one lane per command, in dependency levels.  A copy runs
+        //        as soon as none of the commands its source overlaps is still unfinished (dep_mask);
+        //        overlapping copies read their pattern modulo the distance, so a copy never waits for
+        //        itself.  All traffic is byte-granular LDS; a level's reads precede its writes.
+        {
+            const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(L.stage) + stage_off;
+            // window index of the pattern start; negative when it begins below the window, in which
+            // case only offsets >= far_len (which are inside the window) are dereferenced
+            const uint8_t* src8 = L.win + (int32_t)(src_pos - view.win_base);
+            uint8_t* dst8 = L.win + (copy_dst - view.win_base);
+            uint32_t todo = wave::half_ballot(fast && cp);
+            while (wave::any(todo != 0u)) {
+                clk.count(kPhLevels, 1);
+                const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
+                const uint32_t ready_mask = wave::half_ballot(ready);
+                // the whole pattern in one place (window or staging area): 8-byte pieces, all loads of the
+                // command before its stores; overlapping copies replay the pattern modulo the distance
+                const bool simple = far_len == 0u || far_len == pattern;
+                if (ready && copy <= kShortCopy && simple) {
+                    const uint8_t* b = far_len ? stage8 : src8;
+                    uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                    uint32_t r = 0;
+                    v0 = pattern_source8(b, dist, r);
+                    if (copy > 8u) { r = advance_mod(r, 8u, dist); v1 = pattern_source8(b, dist, r); }
+                    if (copy > 16u) { r = advance_mod(r, 8u, dist); v2 = pattern_source8(b, dist, r); }
+                    if (copy > 24u) { r = advance_mod(r, 8u, dist); v3 = pattern_source8(b, dist, r); }
+                    store_bytes(dst8, v0, copy);
+                    if (copy > 8u) store_bytes(dst8 + 8, v1, copy - 8u);
+                    if (copy > 16u) store_bytes(dst8 + 16, v2, copy - 16u);
+                    if (copy > 24u) store_bytes(dst8 + 24, v3, copy - 24u);
+                }
+                clk.lap(kPhLvShort);
+                const bool rs = ready && copy <= kShortCopy && !simple;     // overlapping or straddling: byte loop
+                // branch-free: inactive lanes read win[0] and write their sink byte, so the four reads
+                // (and then the four writes) of a step issue back to back behind a single wait
+                uint32_t r = 0;
+                for (uint32_t i = 0; wave::any(rs && i < copy); i += 4u) {
+                    const bool a0 = rs && i < copy, a1 = rs && i + 1u < copy, a2 = rs && i + 2u < copy, a3 = rs && i + 3u < copy;
+                    const uint8_t* p0 = a0 ? (r < far_len ? stage8 : src8) + r : L.win; r = r + 1u == dist ? 0u : r + 1u;
+                    const uint8_t* p1 = a1 ? (r < far_len ? stage8 : src8) + r : L.win; r = r + 1u == dist ? 0u : r + 1u;
+                    const uint8_t* p2 = a2 ? (r < far_len ? stage8 : src8) + r : L.win; r = r + 1u == dist ? 0u : r + 1u;
+                    const uint8_t* p3 = a3 ? (r < far_len ? stage8 : src8) + r : L.win; r = r + 1u == dist ? 0u : r + 1u;
+                    const uint8_t b0 = *p0, b1 = *p1, b2 = *p2, b3 = *p3;
+                    wave::sync();
+                    uint8_t* sink = &L.sink[sl];
+                    *(a0 ? dst8 + i : sink) = b0;
+                    *(a1 ? dst8 + i + 1u : sink) = b1;
+                    *(a2 ? dst8 + i + 2u : sink) = b2;
+                    *(a3 ? dst8 + i + 3u : sink) = b3;
+                }
+                clk.lap(kPhLvBytes);
+                uint32_t long_mask = wave::half_ballot(ready && copy > kShortCopy);
+                while (wave::any(long_mask != 0u)) {                    // all 32 lanes per command, 4 bytes per lane per step
+                    const uint32_t k = long_mask ? ctz_u32(long_mask) : 0u;
+                    const uint32_t k_src = wave::half_bcast(src_pos - view.win_base, k), k_dst = wave::half_bcast(copy_dst - view.win_base, k);
+                    const uint32_t k_dist = wave::half_bcast(dist, k), k_len = wave::half_bcast(copy, k);
+                    const uint32_t k_far = wave::half_bcast(far_len, k), k_stage = wave::half_bcast(stage_off, k);
+                    const uint8_t* kst = reinterpret_cast<const uint8_t*>(L.stage) + k_stage;
+                    const uint8_t* ksrc = L.win + (int32_t)k_src;
+                    uint8_t* kdst = L.win + k_dst;
+                    const bool on = long_mask != 0u;
+                    const bool overlap = on && k_dist < k_len;
+                    const uint32_t k_pat = k_dist < k_len ? k_dist : k_len;
+                    const bool k_simple = k_far == 0u || k_far == k_pat;
+                    if (on && k_simple) {                               // 8 bytes per lane per step, four steps in flight
+                        const uint8_t* b = k_far ? kst : ksrc;
+                        uint32_t r8 = overlap ? (8u * sl) % k_dist : 8u * sl;
+                        const uint32_t step8 = overlap ? 256u % k_dist : 256u;
+                        for (uint32_t j = 8u * sl; j < k_len; j += 1024u) {
+                            uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                            v0 = pattern_source8(b, k_dist, r8); r8 = overlap ? advance_mod(r8, step8, k_dist) : r8 + 256u;
+                            if (j + 256u < k_len) { v1 = pattern_source8(b, k_dist, r8); r8 = overlap ? advance_mod(r8, step8, k_dist) : r8 + 256u; }
+                            if (j + 512u < k_len) { v2 = pattern_source8(b, k_dist, r8); r8 = overlap ? advance_mod(r8, step8, k_dist) : r8 + 256u; }
+                            if (j + 768u < k_len) { v3 = pattern_source8(b, k_dist, r8); r8 = overlap ? advance_mod(r8, step8, k_dist) : r8 + 256u; }
+                            store_bytes(kdst + j, v0, k_len - j);
+                            if (j + 256u < k_len) store_bytes(kdst + j + 256u, v1, k_len - j - 256u);
+                            if (j + 512u < k_len) store_bytes(kdst + j + 512u, v2, k_len - j - 512u);
+                            if (j + 768u < k_len) store_bytes(kdst + j + 768u, v3, k_len - j - 768u);
+                        }
+                    }
+                    const bool bytewise = on && !k_simple;              // pattern straddles the window boundary
+                    // lane handles bytes sl, sl + 32, ...; r follows j modulo the distance
+                    uint32_t rl = overlap ? sl % k_dist : sl;
+                    const uint32_t step = overlap ? 32u % k_dist : 32u;
+                    for (uint32_t j0 = 0; wave::any(bytewise && j0 < k_len); j0 += 128u) {
+                        const uint32_t j = j0 + sl;
+                        const bool a0 = bytewise && j < k_len, a1 = bytewise && j + 32u < k_len, a2 = bytewise && j + 64u < k_len, a3 = bytewise && j + 96u < k_len;
+                        const uint8_t* p0 = a0 ? (rl < k_far ? kst : ksrc) + rl : L.win; rl = overlap ? advance_mod(rl, step, k_dist) : rl + 32u;
+                        const uint8_t* p1 = a1 ? (rl < k_far ? kst : ksrc) + rl : L.win; rl = overlap ? advance_mod(rl, step, k_dist) : rl + 32u;
+                        const uint8_t* p2 = a2 ? (rl < k_far ? kst : ksrc) + rl : L.win; rl = overlap ? advance_mod(rl, step, k_dist) : rl + 32u;
+                        const uint8_t* p3 = a3 ? (rl < k_far ? kst : ksrc) + rl : L.win; rl = overlap ? advance_mod(rl, step, k_dist) : rl + 32u;
+                        const uint8_t b0 = *p0, b1 = *p1, b2 = *p2, b3 = *p3;
+                        wave::sync();
+                        uint8_t* sink = &L.sink[sl];
+                        *(a0 ? kdst + j : sink) = b0;
+                        *(a1 ? kdst + j + 32u : sink) = b1;
+                        *(a2 ? kdst + j + 64u : sink) = b2;
+                        *(a3 ? kdst + j + 96u : sink) = b3;
+                    }
+                    long_mask &= long_mask - 1u;
+                }
+                todo &= ~ready_mask;
+                wave::sync();
+                clk.lap(kPhLvLong);
+            }
+        }
+        clk.lap(kPhCopyLevels);
+
+        // -- 5c. round in global memory (more than kRoundMax bytes): LZ77 copies in dependency levels.
+        //        A copy is ready once its source range ends at or below the destination of the first
+        //        unfinished copy; overlapping sources are read modulo the distance, so a copy never
+        //        depends on itself.  Each level's stores are performed before the next level loads.
+        uint32_t todo = wave::half_ballot(slow && cp);
+        if (wave::any(slow)) wave::global_fence();                      // literals just stored, window just flushed
         while (wave::any(todo != 0u)) {
-            const uint32_t first_dst = wave::half_shfl(copy_dst, todo ? ctz_u32(todo) : 0u);
+            const uint32_t first_dst = wave::half_bcast(copy_dst, todo ? ctz_u32(todo) : 0u);
             const bool mine = ((todo >> sl) & 1u) != 0u;
             const bool ready = mine && src_end <= first_dst;
             const uint32_t ready_mask = wave::half_ballot(ready);
             uint32_t long_mask = wave::half_ballot(ready && copy > kShortCopy);
             if (ready && copy <= kShortCopy) {                          // one lane per command, <= 4 chunks of 8 bytes
-                uint8_t* d = job.out + copy_dst;
-                const uint8_t* s = d - dist;
                 uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
                 uint32_t r = 0;
-                v0 = copy_source8(s, dist, r);
-                if (copy > 8u) { r = advance_mod(r, 8u, dist); v1 = copy_source8(s, dist, r); }
-                if (copy > 16u) { r = advance_mod(r, 8u, dist); v2 = copy_source8(s, dist, r); }
-                if (copy > 24u) { r = advance_mod(r, 8u, dist); v3 = copy_source8(s, dist, r); }
-                store_bytes(d, v0, copy);
-                if (copy > 8u) store_bytes(d + 8, v1, copy - 8u);
-                if (copy > 16u) store_bytes(d + 16, v2, copy - 16u);
-                if (copy > 24u) store_bytes(d + 24, v3, copy - 24u);
+                v0 = copy_source8(view, src_pos, dist, r);
+                if (copy > 8u) { r = advance_mod(r, 8u, dist); v1 = copy_source8(view, src_pos, dist, r); }
+                if (copy > 16u) { r = advance_mod(r, 8u, dist); v2 = copy_source8(view, src_pos, dist, r); }
+                if (copy > 24u) { r = advance_mod(r, 8u, dist); v3 = copy_source8(view, src_pos, dist, r); }
+                view.write(copy_dst, v0, copy);
+                if (copy > 8u) view.write(copy_dst + 8u, v1, copy - 8u);
+                if (copy > 16u) view.write(copy_dst + 16u, v2, copy - 16u);
+                if (copy > 24u) view.write(copy_dst + 24u, v3, copy - 24u);
             }
             while (wave::any(long_mask != 0u)) {                        // all 32 lanes per command, 8 bytes per lane per step
                 const uint32_t k = long_mask ? ctz_u32(long_mask) : 0u;
-                const uint32_t cd = wave::half_shfl(copy_dst, k), dd = wave::half_shfl(dist, k);
-                const uint32_t cl = wave::half_shfl(copy, k);
+                const uint32_t cd = wave::half_bcast(copy_dst, k), dd = wave::half_bcast(dist, k);
+                const uint32_t cl = wave::half_bcast(copy, k);
                 if (long_mask) {
-                    uint8_t* d = job.out + cd;
-                    const uint8_t* s = d - dd;
+                    const uint32_t sp = cd - dd;
                     const bool overlap = dd < cl;
                     uint32_t r = overlap ? (8u * sl) % dd : 8u * sl;
                     const uint32_t step = overlap ? 256u % dd : 256u;
                     for (uint32_t j = 8u * sl; j < cl; j += 1024u) {    // up to four chunks in flight per lane
                         uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                        v0 = copy_source8(s, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u;
-                        if (j + 256u < cl) { v1 = copy_source8(s, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
-                        if (j + 512u < cl) { v2 = copy_source8(s, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
-                        if (j + 768u < cl) { v3 = copy_source8(s, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
-                        store_bytes(d + j, v0, cl - j);
-                        if (j + 256u < cl) store_bytes(d + j + 256u, v1, cl - j - 256u);
-                        if (j + 512u < cl) store_bytes(d + j + 512u, v2, cl - j - 512u);
-                        if (j + 768u < cl) store_bytes(d + j + 768u, v3, cl - j - 768u);
+                        v0 = copy_source8(view, sp, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u;
+                        if (j + 256u < cl) { v1 = copy_source8(view, sp, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
+                        if (j + 512u < cl) { v2 = copy_source8(view, sp, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
+                        if (j + 768u < cl) { v3 = copy_source8(view, sp, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
+                        view.write(cd + j, v0, cl - j);
+                        if (j + 256u < cl) view.write(cd + j + 256u, v1, cl - j - 256u);
+                        if (j + 512u < cl) view.write(cd + j + 512u, v2, cl - j - 512u);
+                        if (j + 768u < cl) view.write(cd + j + 768u, v3, cl - j - 768u);
                     }
                 }
                 long_mask &= long_mask - 1u;
@@ -638,11 +986,22 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             todo &= ~ready_mask;
             if (wave::any(todo != 0u)) wave::global_fence();
         }
+        if (slow) {                                                     // the window restarts empty after a global round
+            flushed = out_pos + round_bytes;
+            view.valid_from = flushed;
+            view.win_base = flushed & ~15u;
+        }
 
+        clk.lap(kPhSlow);
         out_pos += round_bytes;
         if (sent_mask) live = false;
     }
 
+    wave::sync();
+    if (wave::any(windowed)) {
+        view.use_win = true;
+        if (windowed) flushed = flush_window(view, flushed, out_pos, true, sl);
+    }
     if (job.valid && !stored && out_pos != job.out_size) bad = true;      // a valid page fills its output exactly
 
     // ---- per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): a running byte
@@ -668,6 +1027,8 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
         }
     }
     if (wave::any(bad) && bad && sl == 0u) atomicOr(status, kStatusBadPage);
+    clk.lap(kPhDelta);
+    clk.flush(prof, lane);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -786,7 +1147,7 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
             }
         }
         const uint32_t lo = wave::half_scan_incl(pages);
-        const uint32_t lo_total = wave::half_shfl(lo, 31);
+        const uint32_t lo_total = wave::half_bcast(lo, 31);
         const uint32_t first_half_total = wave::bcast(lo_total, 0);
         const uint32_t second_half_total = wave::bcast(lo_total, 32);
         const uint32_t incl = lane < 32u ? lo : lo + first_half_total;
@@ -797,7 +1158,8 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
 }
 
 // Kernel 2: persistent waves pull page pairs until the counter runs out.
-__global__ void __launch_bounds__(64) brotlig_decode_kernel(DecodeArgs a)
+template <bool kProf>
+__device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
 {
     __shared__ WaveLds W;
     const uint32_t lane = wave::lane_id();
@@ -845,9 +1207,13 @@ __global__ void __launch_bounds__(64) brotlig_decode_kernel(DecodeArgs a)
                 atomicOr(a.status, kStatusBadPage);
             }
         }
-        decode_page_pair(W, job, a.status);
+        decode_page_pair<kProf>(W, job, a.status, a.prof);
     }
 }
+
+__global__ void __launch_bounds__(64) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }
+// Diagnostics twin: same code with s_memtime phase timers (BrotligDecodePhaseProfile).
+__global__ void __launch_bounds__(64) brotlig_decode_kernel_timed(DecodeArgs a) { decode_kernel_body<true>(a); }
 
 // Device self-test of the cross-lane primitives (results checked on the host).
 __global__ void __launch_bounds__(64) brotlig_selftest_kernel(uint32_t* out)
@@ -858,6 +1224,7 @@ __global__ void __launch_bounds__(64) brotlig_selftest_kernel(uint32_t* out)
     out[64 + lane] = wave::half_scan_incl_ref(v);
     out[128 + lane] = wave::half_ballot((v & 1u) != 0u);
     out[192 + lane] = wave::half_shfl(v, lane * 7u + 3u);
+    out[384 + lane] = wave::half_bcast(v, (lane & 32u) ? 5u : 29u);    // source lane uniform within each half
     out[256 + lane] = wave::half_max(v);
     out[320 + lane] = v;
 }

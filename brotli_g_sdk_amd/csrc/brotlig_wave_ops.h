@@ -23,6 +23,9 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src)
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((src & 63u) << 2), (int)v);
 }
 
+// Shader clock (s_memtime), for the phase-timer diagnostics build.
+__device__ __forceinline__ unsigned long long clock() { return (unsigned long long)__builtin_readcyclecounter(); }
+
 // ---- half scope -------------------------------------------------------------------------
 // 32-bit ballot of the caller's half.
 __device__ __forceinline__ uint32_t half_ballot(bool p)
@@ -36,6 +39,18 @@ __device__ __forceinline__ uint32_t half_shfl(uint32_t v, uint32_t src)
 {
     const uint32_t lane = (lane_id() & 32u) | (src & 31u);
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane << 2), (int)v);
+}
+
+// Same, for a source lane that is uniform within each half (the usual case: an index derived
+// from a half ballot, or a constant).  Two v_readlane per half instead of a trip through the LDS
+// crossbar: no lgkmcnt latency on the critical path.
+__device__ __forceinline__ uint32_t half_bcast(uint32_t v, uint32_t src)
+{
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)src) & 31u;
+    const uint32_t s1 = ((uint32_t)__builtin_amdgcn_readlane((int)src, 32) & 31u) | 32u;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s0);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)s1);
+    return lane_id() < 32u ? a : b;
 }
 
 // Inclusive prefix sum over the caller's half.  DPP row shifts cover the 16-lane rows;
@@ -65,7 +80,7 @@ __device__ __forceinline__ uint32_t half_scan_incl_ref(uint32_t v)
     return x;
 }
 
-__device__ __forceinline__ uint32_t half_sum(uint32_t v) { return half_shfl(half_scan_incl(v), 31); }
+__device__ __forceinline__ uint32_t half_sum(uint32_t v) { return half_bcast(half_scan_incl(v), 31); }
 
 // Maximum over the caller's half.
 __device__ __forceinline__ uint32_t half_max(uint32_t v)
@@ -78,15 +93,23 @@ __device__ __forceinline__ uint32_t half_max(uint32_t v)
     return x;
 }
 
-// LDS hand-off between lanes of the wave (workgroup == one wave).
-__device__ __forceinline__ void sync() { __syncthreads(); }
+// LDS hand-off between lanes of the wave.  The workgroup is exactly one wave and the LDS
+// pipeline executes a wave's DS instructions in issue order, so all this has to do is stop the
+// compiler from moving LDS accesses across it.  (__syncthreads() would also work but carries
+// s_waitcnt vmcnt(0) + s_barrier, i.e. a full global-memory drain on every call.)
+__device__ __forceinline__ void sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-// Global-memory hand-off between lanes of the wave: earlier stores by any lane of this
-// workgroup are visible to later loads by any lane (same CU, shared vector L1).
+// Global-memory hand-off between lanes of the wave: earlier stores by any lane of this wave are
+// visible to later loads by any lane (one CU, one vector L1; the release drains vmcnt so the
+// stores have been performed before the loads issue).
 __device__ __forceinline__ void global_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 

@@ -108,6 +108,16 @@ BROTLIG_ERROR BrotligDecodeBatchTimed(const void* d_in, uint64_t in_bytes, void*
  * half-wave ballot / shuffle / max).  Returns BROTLIG_OK when they agree. */
 BROTLIG_ERROR BrotligDeviceSelfTest(void);
 
+/* Diagnostics: decodes the batch once with the phase-timer twin of the decode kernel and returns
+ * per-phase shader-clock sums over all page pairs (s_memtime deltas of lane 0 of every wave).
+ * cycles_out[0..11] = setup, tables, commands, ring, positions, literals, copy-fence, copy-levels,
+ * delta, total, number of rounds, number of copy levels, then the level sub-phases (wide short
+ * copies, byte-wise copies, long copies) and rounds assembled in global memory.  Synchronous. */
+BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
+                                        const BrotligStreamDesc* d_streams, uint32_t num_streams,
+                                        void* d_workspace, size_t workspace_bytes, void* d_scratch,
+                                        uint64_t* cycles_out, uint32_t n_out);
+
 /* Static properties, for reports: LDS bytes per workgroup, workgroups launched. */
 uint32_t BrotligKernelLdsBytes(void);
 uint32_t BrotligKernelGridSize(void);

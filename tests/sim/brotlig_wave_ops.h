@@ -10,6 +10,7 @@ inline uint32_t lane_id() { return sim::lane_now() & 63u; }
 
 #define SIM_SITE int site = __builtin_LINE()
 
+inline unsigned long long clock() { return (unsigned long long)__builtin_ia32_rdtsc(); }
 inline uint64_t ballot64(bool p, SIM_SITE)
 {
     const int s = sim::collective_enter(p ? 1 : 0, 0, site);
@@ -28,6 +29,17 @@ inline uint32_t half_shfl(uint32_t v, uint32_t src, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);
     return (uint32_t)sim::g_wave.in_a[s][(lane_id() & 32u) | (src & 31u)];
+}
+inline uint32_t half_bcast(uint32_t v, uint32_t src, SIM_SITE)
+{
+    // the device version requires `src` to be uniform within each half: check it
+    const int s = sim::collective_enter(v, src, site);
+    const uint32_t base = lane_id() & 32u;
+    for (uint32_t l = base; l < base + 32u; ++l)
+        if (!sim::g_wave.fiber[l].done && sim::g_wave.in_b[s][l] != src) {
+            fprintf(stderr, "SIM: half_bcast with a non-uniform source lane at line %d\n", site); abort();
+        }
+    return (uint32_t)sim::g_wave.in_a[s][base | (src & 31u)];
 }
 inline uint32_t half_scan_incl(uint32_t v, SIM_SITE)
 {

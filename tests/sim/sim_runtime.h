@@ -93,3 +93,4 @@ inline uint32_t __brev(uint32_t x)
 }
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }

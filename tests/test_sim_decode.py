@@ -95,10 +95,11 @@ def test_sim_bad_header_sets_status(sim):
 
 
 def test_sim_wave_primitives(sim):
-    out = np.zeros(384, np.uint32)
+    out = np.zeros(448, np.uint32)
     sim.sim_selftest(out.ctypes.data)
     v = out[320:384]
     for lane in range(64):
         base = lane & 32
         assert out[lane] == v[base:lane + 1].sum() == out[64 + lane]
         assert out[256 + lane] == v[base:base + 32].max()
+        assert out[384 + lane] == v[base + (5 if base else 29)]
