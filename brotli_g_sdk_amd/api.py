@@ -161,8 +161,8 @@ class BatchDecoder:
                 raise BrotligError(rc, "BrotligDecodeBatchStatus")
             return total.value, kern.value
 
-    PHASES = ("setup", "tables", "commands", "ring", "positions", "literals", "copy_fence", "copy_levels",
-              "delta", "total", "rounds", "levels", "lv_short", "lv_bytes", "lv_long", "slow_round")
+    PHASES = ("setup", "tables", "commands", "ring", "positions", "literals", "group_setup", "level_tail",
+              "delta", "total", "rounds", "levels", "lv_short", "lv_bytes", "lv_long_and_far", "unused")
 
     def phase_profile(self):
         """Per-phase shader-clock sums from the phase-timer twin of the decode kernel (diagnostics)."""

@@ -85,7 +85,7 @@ template <> struct PhaseClock<true> {
 };
 
 // ---- tunables ---------------------------------------------------------------------------
-constexpr int kLutBitsIcp = 10;
+constexpr int kLutBitsIcp = 9;
 constexpr int kLutBitsDist = 9;
 constexpr int kLutBitsLit = 9;
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index
@@ -94,8 +94,8 @@ constexpr uint32_t kShortCopy = 32;         // copies up to this length run one-
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
 // flushed to global memory in aligned 16-byte stores when it slides.
-constexpr uint32_t kWin = 2048;
-constexpr uint32_t kHist = 1024;            // history kept across a slide (>= kWin / 2: see slide_window)
+constexpr uint32_t kWin = 1792;
+constexpr uint32_t kHist = 896;             // history kept across a slide (>= kWin / 2: see the slide below)
 constexpr uint32_t kRoundMax = kWin - kHist;
 constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
 
@@ -125,15 +125,13 @@ struct __attribute__((aligned(16))) PageLds {
     uint16_t sorted_icp[kIcpAlphabet];
     uint16_t sorted_dist[kDistAlphabet];
     uint16_t sorted_lit[kLitAlphabet];
-    uint16_t limit[3][16];      // per code length: exclusive upper bound, left-justified to 15 bits
-    uint16_t first[3][16];      // first code of the length, left-justified
-    uint16_t offs[3][16];       // index of the first symbol of the length in sorted_*
-    uint32_t round_ins_incl[32];    // per round: inclusive prefix of insert lengths
-    uint32_t round_copy_excl[32];   // per round: exclusive prefix of copy lengths
-    uint32_t start_bits[kRoundMax / 32];    // per round: bit p set <=> a command starts at round byte p
-    uint32_t start_cum[kRoundMax / 32];     // per round: command starts in earlier words of start_bits
-    uint32_t lit_bits[kRoundMax / 32 + 2];  // per round: bit j set <=> decoded literal j is the first of a literal run
-    uint32_t lit_shift[32];                 // per round: copy bytes preceding the r-th literal run
+    uint16_t limit[3][16] __attribute__((aligned(16)));     // per code length: exclusive upper bound, left-justified to 15 bits
+    uint32_t first_offs[3][16]; // per code length: first code (left-justified) | index of its first symbol in sorted_* << 16
+    uint32_t start_bits[kRoundMax / 32];    // per group: bit p set <=> a command's piece starts at group byte p
+    uint32_t lit_bits[kRoundMax / 32];      // per group: bit i set <=> the group's i-th literal starts a literal run
+    uint8_t  start_cum[kRoundMax / 32];     // per group: piece starts in earlier words of start_bits
+    uint8_t  lit_cum[kRoundMax / 32];       // per group: run starts in earlier words of lit_bits
+    uint32_t lit_shift[32];                 // per group: (round-relative position - consumption index) of the r-th run
     uint64_t stage[kStageBytes / 8];        // per round: source bytes of far copies (older than the window)
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
     uint8_t  sink[64];              // write target of inactive lanes in branch-free copy loops
@@ -209,52 +207,18 @@ __device__ __forceinline__ void store_bytes(uint8_t* p, uint64_t v, uint32_t n)
     if (n & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); p += 2; v >>= 16; }
     if (n & 1u) *p = (uint8_t)v;
 }
-// Where a page's bytes are while it is being decoded: positions >= valid_from are in the LDS window
-// (win[pos - win_base]); everything below `flushed` is in global memory (out[pos]).
+// Where a page's bytes are while it is being decoded: positions >= win_base are in the LDS window
+// (win[pos - win_base]); everything below `flushed` (tracked by the caller) is in global memory.
 struct OutView {
     uint8_t* out;
     uint8_t* win;
     uint32_t win_base;      // page position of win[0]; multiple of 16
-    uint32_t valid_from;    // window holds [valid_from, frontier)
-    bool     use_win;       // this round is assembled in the window (else straight in global memory)
-
-    __device__ __forceinline__ uint64_t read8(uint32_t pos) const
-    {
-        if (!use_win || pos + 8u <= valid_from) return load_u64u(out + pos);
-        if (pos >= valid_from) return load_u64u(win + (pos - win_base));
-        const uint32_t n = valid_from - pos;                        // 1..7 bytes still only in global memory
-        const uint64_t lo = load_u64u(out + pos), hi = load_u64u(win + (valid_from - win_base));
-        return (lo & ((1ull << (8u * n)) - 1ull)) | (hi << (8u * n));
-    }
-    __device__ __forceinline__ void write(uint32_t pos, uint64_t v, uint32_t n) const
-    {
-        store_bytes(use_win ? win + (pos - win_base) : out + pos, v, n);
-    }
-    __device__ __forceinline__ void put(uint32_t pos, uint32_t byte) const
-    {
-        if (use_win) win[pos - win_base] = (uint8_t)byte; else out[pos] = (uint8_t)byte;
-    }
 };
 
-// Eight bytes of an LZ77 copy's source, starting at offset r (< d) of its period: byte k is
-// page[sp + (r + k) mod d].  For d >= copy length this is a plain read; for overlapping copies it
-// replays the first d bytes, so no byte written by the copy itself is ever read back
-// (out[t + j] = out[t - d + (j mod d)], PageDecoder.cpp:219-232 / BrotliGCompute.hlsl:1414-1418).
-__device__ __forceinline__ uint64_t copy_source8(const OutView& o, uint32_t sp, uint32_t d, uint32_t r)
-{
-    if (r + 8u <= d) return o.read8(sp + r);
-    if (d >= 8u) {
-        const uint32_t n = d - r;                                   // 1..7 bytes before the period wraps
-        const uint64_t lo = o.read8(sp + r), hi = o.read8(sp);
-        return (lo & ((1ull << (8u * n)) - 1ull)) | (hi << (8u * n));
-    }
-    const uint64_t p = o.read8(sp);
-    uint64_t v = 0;
-    uint32_t idx = r;
-    for (uint32_t k = 0; k < 8u; ++k) { v |= ((p >> (8u * idx)) & 0xFFull) << (8u * k); if (++idx == d) idx = 0; }
-    return v;
-}
-// Same as copy_source8, for a pattern that lies entirely in LDS at `s`.
+// Eight bytes of an LZ77 copy's source pattern (which lies entirely in LDS at `s`), starting at offset
+// r (< d) of its period: byte k is s[(r + k) mod d].  For d >= copy length this is a plain read; for
+// overlapping copies it replays the first d bytes, so no byte written by the copy itself is ever read
+// back (out[t + j] = out[t - d + (j mod d)], PageDecoder.cpp:219-232 / BrotliGCompute.hlsl:1414-1418).
 __device__ __forceinline__ uint64_t pattern_source8(const uint8_t* s, uint32_t d, uint32_t r)
 {
     if (r + 8u <= d) return load_u64u(s + r);
@@ -269,6 +233,41 @@ __device__ __forceinline__ uint64_t pattern_source8(const uint8_t* s, uint32_t d
     for (uint32_t k = 0; k < 8u; ++k) { v |= ((p >> (8u * idx)) & 0xFFull) << (8u * k); if (++idx == d) idx = 0; }
     return v;
 }
+// Position of the q-th (0-based) set bit of m; q < popcount(m).
+__device__ __forceinline__ uint32_t select_bit(uint32_t m, uint32_t q)
+{
+    uint32_t pos = 0, c;
+    c = (uint32_t)__popc(m & 0xFFFFu); if (q >= c) { q -= c; pos += 16u; m >>= 16; }
+    c = (uint32_t)__popc(m & 0xFFu);   if (q >= c) { q -= c; pos += 8u;  m >>= 8; }
+    c = (uint32_t)__popc(m & 0xFu);    if (q >= c) { q -= c; pos += 4u;  m >>= 4; }
+    c = (uint32_t)__popc(m & 0x3u);    if (q >= c) { q -= c; pos += 2u;  m >>= 2; }
+    c = m & 1u;                        if (q >= c) { pos += 1u; }
+    return pos;
+}
+// j mod d for j < 2^16, d >= 1: reciprocal estimate plus one correction either way.
+__device__ __forceinline__ uint32_t mod_u16(uint32_t j, uint32_t d)
+{
+    const uint32_t q = (uint32_t)((float)j * __builtin_amdgcn_rcpf((float)d));
+    int32_t rem = (int32_t)(j - q * d);
+    if (rem < 0) rem += (int32_t)d;
+    if ((uint32_t)rem >= d) rem -= (int32_t)d;
+    return (uint32_t)rem;
+}
+// Teams: `count` jobs share the 32 lanes of a half; each job gets 32 >> ceil_log2(count) lanes.
+struct Team { uint32_t log2_size; uint32_t job; uint32_t member; bool serves; };
+__device__ __forceinline__ Team make_team(uint32_t job_mask, uint32_t sl)
+{
+    const uint32_t count = (uint32_t)__popc(job_mask);
+    const uint32_t need = count <= 1u ? 0u : 32u - (uint32_t)__clz((int)(count - 1u));     // ceil_log2(count)
+    Team t;
+    t.log2_size = 5u - need;
+    const uint32_t q = sl >> t.log2_size;
+    t.member = sl & ((1u << t.log2_size) - 1u);
+    t.serves = q < count;
+    t.job = select_bit(job_mask, t.serves ? q : 0u);               // lane (0..31) of the piece this team serves
+    return t;
+}
+
 // Store window bytes [from, to) of the page to global memory: up to 15 head bytes, then aligned
 // 16-byte pieces (one per lane per step), then -- only when `exact` -- the tail bytes.  Without
 // `exact` the range is cut at the last 16-byte boundary.  Returns the new flushed position.
@@ -297,21 +296,34 @@ __device__ __forceinline__ uint32_t advance_mod(uint32_t r, uint32_t step, uint3
 
 // One prefix-code table: which LDS arrays it lives in.
 struct TableRef {
-    uint16_t* lut; uint16_t* sorted; uint16_t* limit; uint16_t* first; uint16_t* offs;
+    uint16_t* lut; uint16_t* sorted; uint16_t* limit; uint32_t* first_offs;
     uint32_t alphabet; int lut_bits;
 };
 
 // Decode one symbol from `br` (needs avail >= 15 on entry).  Returns symbol, sets len.
+// kBits = index width of the table's primary LUT.  Codes longer than that take the canonical route:
+// the limits of lengths 8..15 arrive in one aligned 16-byte LDS read (same address for the whole
+// half), the length is a count of compares, then one read for {first code, offset} and one for the
+// symbol -- two dependent reads instead of a search loop.
+template <int kBits>
 __device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitReader& br, uint32_t& len)
 {
+    static_assert(kBits >= 7 && kBits <= 14, "limit words 8..15 must cover every long length");
     const uint32_t bits = (uint32_t)br.buf;
-    const uint32_t e = t.lut[bits & ((1u << t.lut_bits) - 1u)];
+    const uint32_t e = t.lut[bits & ((1u << kBits) - 1u)];
     if (e != kLongCode) { len = e & 15u; return e >> 4; }
-    // canonical fallback for codes longer than the LUT index
     const uint32_t v = __brev(bits) >> 17;                      // next 15 bits, MSB-first
-    uint32_t l = (uint32_t)t.lut_bits + 1u;
-    while (l < 15u && v >= t.limit[l]) ++l;
-    uint32_t idx = t.offs[l] + ((v - t.first[l]) >> (15u - l));
+    uint32_t lim[4];
+    __builtin_memcpy(lim, t.limit + 8, 16);                     // limits of lengths 8..15, two per word
+    uint32_t l = (uint32_t)kBits + 1u;
+#pragma unroll
+    for (int k = kBits + 1; k < 15; ++k) {
+        const uint32_t w = lim[(k - 8) >> 1];
+        const uint32_t lk = (k & 1) ? (w >> 16) : (w & 0xFFFFu);
+        l += v >= lk ? 1u : 0u;
+    }
+    const uint32_t fo = t.first_offs[l];
+    uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
     idx = min_u32(idx, t.alphabet - 1u);
     len = l;
     return t.sorted[idx];
@@ -420,9 +432,8 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
             if (is_complex) cnt[l * 32u + sl] = (uint16_t)(off + incl - c);
             code = (code + prev_count) << 1;
             if (is_complex && sl == 0u) {
-                t.first[l] = (uint16_t)min_u32(code << (15u - l), 32768u);
                 t.limit[l] = (uint16_t)min_u32((code + total) << (15u - l), 32768u);
-                t.offs[l] = (uint16_t)off;
+                t.first_offs[l] = min_u32(code << (15u - l), 32768u) | (off << 16);
             }
             off += total; prev_count = total;
         }
@@ -441,7 +452,8 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
                 while (l <= (uint32_t)t.lut_bits && v >= t.limit[l]) ++l;
                 uint32_t entry = kLongCode;
                 if (l <= (uint32_t)t.lut_bits) {
-                    uint32_t idx = t.offs[l] + ((v - t.first[l]) >> (15u - l));
+                    const uint32_t fo = t.first_offs[l];
+                    uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
                     idx = min_u32(idx, A - 1u);
                     entry = ((uint32_t)t.sorted[idx] << 4) | l;
                 }
@@ -533,9 +545,9 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
 
     clk.lap(kPhSetup);
     // ---- three prefix codes: ICP, distance, literal (PageDecoder.cpp:125-147)
-    const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first[0], L.offs[0], kIcpAlphabet, kLutBitsIcp};
-    const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first[1], L.offs[1], kDistAlphabet, kLutBitsDist};
-    const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first[2], L.offs[2], kLitAlphabet, kLutBitsLit};
+    const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first_offs[0], kIcpAlphabet, kLutBitsIcp};
+    const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist};
+    const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit};
     build_table(t_icp, L, br, live, sl);
     build_table(t_dist, L, br, live, sl);
     build_table(t_lit, L, br, live, sl);
@@ -548,14 +560,14 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
     uint32_t carry_head = 0;
     uint32_t rounds_left = job.page_size / 64u + 4u;                    // every full round emits >= 64 bytes
     bool bad = false;
-    OutView view{job.out, L.win, 0u, 0u, true};
+    OutView view{job.out, L.win, 0u};
     uint32_t flushed = 0;            // page bytes below this are in global memory
     const bool windowed = live;      // this half decodes a compressed page (and owes a final flush)
 
     while (wave::any(live)) {
         // -- 1. one command per lane
         uint32_t sym = 0, len = 0;
-        if (live) { br.ensure(15); sym = decode_symbol(t_icp, br, len); }
+        if (live) { br.ensure(15); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
         const uint32_t sent_mask = wave::half_ballot(live && sym == kSentinel);
         const uint32_t n = sent_mask ? ctz_u32(sent_mask) : 32u;
         const bool is_cmd = live && sl < n;
@@ -573,7 +585,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
                 if (sym >= 128u) {                                      // explicit distance symbol
                     uint32_t dl;
                     br.ensure(15);
-                    dcode = decode_symbol(t_dist, br, dl);
+                    dcode = decode_symbol<kLutBitsDist>(t_dist, br, dl);
                     br.consume(dl);
                     if (dcode >= 16u) {                                 // PageDecoder.cpp:365-390
                         if (dcode < 16u + ndirect) dist = dcode - 15u;
@@ -653,353 +665,238 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
         }
         const bool ok_cmd = is_cmd && live;
 
-        L.round_ins_incl[sl] = incl_ins;
-        L.round_copy_excl[sl] = (incl_tot - tot) - (incl_ins - ins);
-
-        // -- 3b. output window: a round of at most kRoundMax bytes is assembled in LDS; make room
-        //        for it (flush + slide) first.  Bigger rounds go straight through global memory:
-        //        everything the window holds is flushed, and the window restarts empty after them.
-        const bool fast = live && round_bytes <= kRoundMax;
-        const bool slow = live && !fast;
-        const bool slide = fast && out_pos + round_bytes > view.win_base + kWin;
-        wave::sync();
-        if (wave::any(slide || slow)) {
-            if (slide || slow) flushed = flush_window(view, flushed, out_pos, slow, sl);
-            // keep kHist bytes of history.  kHist >= kWin / 2, so every byte flushed by THIS slide is
-            // still inside the window: reads from global memory only ever touch bytes flushed by an
-            // earlier slide.  The move runs 256 bytes per step (8 per lane), all reads of a step before
-            // its writes; the destination trails the source, so no unread byte is overwritten.
-            const uint32_t nb = slide ? (out_pos - kHist) & ~15u : view.win_base;
-            const uint32_t shift = nb - view.win_base, count = shift ? out_pos - nb : 0u;
-            for (uint32_t i0 = 0; wave::any(i0 < count); i0 += 256u) {
-                const uint32_t i = i0 + 8u * sl;
-                const uint64_t v = i < count ? load_u64u(view.win + shift + i) : 0ull;
-                wave::sync();
-                if (i < count) __builtin_memcpy(view.win + i, &v, 8);
-                wave::sync();
-            }
-            if (slide) {
-                view.win_base = nb;
-                if (view.valid_from < nb) view.valid_from = nb;
-            }
-        }
-        wave::sync();
-        view.use_win = fast;
-
-        // -- 3c. windowed round: per-round lookup structures, and the loads of far copies (sources
-        //        older than the window) issued early so that they fly during the literal decode
-        const uint32_t span0 = out_pos - view.win_base;                 // window index of the round's first byte
-        const uint32_t src_pos = copy_dst - dist;
-        const bool do_copy = ok_cmd && copy > 0u;
+        // literal bookkeeping of the round (PageDecoder.cpp:196-199)
+        const uint32_t lit_a = incl_ins - ins;                          // my literals are consumption indices [lit_a, lit_a + ins)
+        const uint32_t rel0 = incl_tot - tot;                           // my first byte, relative to the round
+        const uint32_t ac = litcount > prev_tail ? litcount - prev_tail : 0u;
+        const uint32_t mult = (live && n) ? (ac + n - 1u) / n : 0u;
+        const uint32_t rlit = n * mult;                                 // literals decoded this round (0 when !live)
+        uint32_t next_j = sl;                                           // next literal of the round this lane decodes
         const bool dist_ok = dist != 0u && dist <= copy_dst;
-        if (do_copy && !dist_ok) bad = true;
-        const bool cp = do_copy && dist_ok;
-        // the first far_len bytes of the copy's source pattern lie below the window and are fetched
-        // from global memory into the staging area; the rest of the pattern is read from the window
-        const uint32_t pattern = min_u32(copy, dist);
-        const uint32_t src_end = src_pos + pattern;
-        const uint32_t far_len = (fast && cp && src_pos < view.valid_from) ? min_u32(pattern, view.valid_from - src_pos) : 0u;
-        const bool far_short = far_len != 0u && far_len <= kShortCopy;
-        const uint32_t stage_len = (far_len + 7u) & ~7u;
-        const uint32_t stage_incl = wave::half_scan_incl(stage_len);
-        const uint32_t stage_off = stage_incl - stage_len;              // 8-byte aligned offset into L.stage
-        uint64_t f0 = 0, f1 = 0, f2 = 0, f3 = 0;
-        if (far_short) {
-            const uint8_t* s = job.out + src_pos;
-            f0 = load_u64u(s);
-            if (far_len > 8u) f1 = load_u64u(s + 8);
-            if (far_len > 16u) f2 = load_u64u(s + 16);
-            if (far_len > 24u) f3 = load_u64u(s + 24);
-        }
-        // literal runs: command k consumes literals [lit_a, lit_b) of the round; the ones at or past
-        // prev_tail are decoded this round (decoded literal j is consumption index prev_tail + j)
-        const uint32_t lit_a = incl_ins - ins, lit_b = incl_ins;
-        const bool has_run = fast && ok_cmd && lit_b > prev_tail && ins > 0u;
-        const uint32_t run_mask = wave::half_ballot(has_run);
-        if (fast) {
-            L.start_bits[sl] = 0u;
-            L.lit_bits[sl] = 0u;
-            if (sl < 2u) L.lit_bits[32u + sl] = 0u;
-        }
-        wave::sync();
-        if (fast && ok_cmd) {
-            const uint32_t rel = cmd_out - out_pos;
-            atomicOr(&L.start_bits[rel >> 5], 1u << (rel & 31u));
-            if (has_run) {
-                const uint32_t j0 = lit_a > prev_tail ? lit_a - prev_tail : 0u;
-                atomicOr(&L.lit_bits[j0 >> 5], 1u << (j0 & 31u));
-                L.lit_shift[__popc(run_mask & ((1u << sl) - 1u))] = (incl_tot - tot) - lit_a;   // copy bytes before the run
+        if (ok_cmd && copy > 0u && !dist_ok) bad = true;
+        const bool cp = ok_cmd && copy > 0u && dist_ok;
+        clk.lap(kPhPositions);
+
+        // The round's output is assembled in the LDS window in byte ranges ("groups") of at most
+        // kRoundMax bytes -- nearly always a single group.  A command that crosses a group boundary
+        // contributes a piece to each group; a copy piece past the first is an ordinary copy from
+        // `dist` bytes back (its earlier bytes are final by then).
+        const uint32_t ngroups = live ? (round_bytes + kRoundMax - 1u) / kRoundMax : 0u;
+        for (uint32_t g = 0; wave::any(g < ngroups); ++g) {
+            const bool on = g < ngroups;
+            const uint32_t g0 = g * kRoundMax, g1 = on ? min_u32(round_bytes, g0 + kRoundMax) : g0;
+            const uint32_t gpos = out_pos + g0;                         // page position of the group's first byte
+
+            // -- 3b. make room in the window: flush finished bytes (aligned 16-byte stores), then slide,
+            //        keeping kHist >= kWin / 2 bytes of history: every byte flushed by THIS slide is still
+            //        inside the window, so reads from global memory only touch bytes flushed by an earlier
+            //        slide.  The move runs 256 bytes per step, all reads of a step before its writes; the
+            //        destination trails the source, so no unread byte is overwritten.
+            const bool slide = on && out_pos + g1 > view.win_base + kWin;
+            wave::sync();
+            if (wave::any(slide)) {
+                if (slide) flushed = flush_window(view, flushed, gpos, false, sl);
+                const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
+                const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
+                for (uint32_t i0 = 0; wave::any(i0 < count); i0 += 256u) {
+                    const uint32_t i = i0 + 8u * sl;
+                    const uint64_t v = i < count ? load_u64u(view.win + shift + i) : 0ull;
+                    wave::sync();
+                    if (i < count) __builtin_memcpy(view.win + i, &v, 8);
+                    wave::sync();
+                }
+                view.win_base = nb;
             }
-        }
-        wave::sync();
-        {
-            const uint32_t w = fast ? L.start_bits[sl] : 0u;
-            const uint32_t cum = wave::half_scan_incl((uint32_t)__popc(w));
-            if (fast) L.start_cum[sl] = cum - (uint32_t)__popc(w);
-        }
-        wave::sync();
-        // exact dependencies of my copy: the commands (before me) whose output overlaps my source
-        uint32_t dep_mask = 0;
-        if (fast && cp && src_end > out_pos) {
-            const uint32_t hi_rel = src_end - 1u - out_pos;
-            const uint32_t hi = L.start_cum[hi_rel >> 5] + (uint32_t)__popc(L.start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
-            uint32_t lo = 0;
-            if (src_pos > out_pos) {
-                const uint32_t lo_rel = src_pos - out_pos;
-                lo = L.start_cum[lo_rel >> 5] + (uint32_t)__popc(L.start_bits[lo_rel >> 5] & (0xFFFFFFFFu >> (31u - (lo_rel & 31u)))) - 1u;
+            wave::sync();
+            const uint32_t span0 = gpos - view.win_base;                // window index of the group's first byte
+
+            // -- 3c. my pieces in this group
+            const uint32_t cs = rel0 + ins;                             // my copy starts here (round-relative)
+            const bool in_group = on && ok_cmd && rel0 < g1 && rel0 + tot > g0;
+            const uint32_t la = rel0 > g0 ? rel0 : g0, lb = cs < g1 ? cs : g1;
+            const uint32_t nlit = (in_group && lb > la) ? lb - la : 0u;     // my literal bytes in the group
+            const uint32_t lit_f = lit_a + (la - rel0);                 // consumption index of the first of them
+            const uint32_t ca = cs > g0 ? cs : g0, cb = rel0 + tot < g1 ? rel0 + tot : g1;
+            const uint32_t plen = (in_group && cp && cb > ca) ? cb - ca : 0u;       // my copy bytes in the group
+            const uint32_t pdst = out_pos + ca;                         // page position of the piece
+            const uint32_t psrc = pdst - dist;
+            const uint32_t pattern = min_u32(plen, dist);
+            const uint32_t src_end = psrc + pattern;
+            // the first far_len bytes of the pattern lie below the window: fetched from global memory
+            // into the staging area (loads issued now, consumed after the literal decode)
+            const uint32_t far_len = (plen && psrc < view.win_base) ? min_u32(pattern, view.win_base - psrc) : 0u;
+            const uint32_t stage_len = (far_len + 7u) & ~7u;
+            const uint32_t stage_incl = wave::half_scan_incl(stage_len);
+            const uint32_t stage_off = stage_incl - stage_len;          // 8-byte aligned offset into L.stage
+            // team loads: every far piece gets a team of lanes; each lane fetches up to two 8-byte chunks
+            // now (consumed after the literal decode), the rare remainder later
+            const uint32_t far_mask = wave::half_ballot(far_len != 0u);
+            const Team ft = make_team(far_mask, sl);
+            const uint32_t ft_src = wave::half_shfl(psrc, ft.job), ft_len = wave::half_shfl(far_len, ft.job);
+            const uint32_t ft_stage = wave::half_shfl(stage_off, ft.job);
+            const uint32_t ft_c0 = ft.member, ft_c1 = ft.member + (1u << ft.log2_size);
+            const bool ft_a0 = ft.serves && far_mask && 8u * ft_c0 < ft_len, ft_a1 = ft.serves && far_mask && 8u * ft_c1 < ft_len;
+            uint64_t fe0 = 0, fe1 = 0;
+            if (ft_a0) fe0 = load_u64u(job.out + ft_src + 8u * ft_c0);
+            if (ft_a1) fe1 = load_u64u(job.out + ft_src + 8u * ft_c1);
+            // literals of the group: consumption indices [F0, F1)
+            const uint32_t mine_before = (on && ok_cmd) ? (cs <= g0 ? ins : (rel0 < g0 ? g0 - rel0 : 0u)) : 0u;   // my literals before g0
+            const uint32_t F0 = wave::half_sum(mine_before);
+            const uint32_t F1 = F0 + wave::half_sum(nlit);
+            const uint32_t run_mask = wave::half_ballot(nlit != 0u);
+            const uint32_t piece_mask = wave::half_ballot(in_group);
+            if (on && sl < kRoundMax / 32u) {
+                L.start_bits[sl] = 0u;
+                L.lit_bits[sl] = 0u;
             }
-            // commands lo .. hi-1 own bytes of [src_pos, src_end); only those before me can be unfinished
-            dep_mask = (hi >= 32u ? 0xFFFFFFFFu : (1u << hi) - 1u) & ~((1u << lo) - 1u) & ((1u << sl) - 1u);
+            wave::sync();
+            if (in_group) {
+                const uint32_t b = (rel0 > g0 ? rel0 : g0) - g0;        // my first byte in the group
+                atomicOr(&L.start_bits[b >> 5], 1u << (b & 31u));
+                if (nlit) {
+                    const uint32_t j0 = lit_f - F0;
+                    atomicOr(&L.lit_bits[j0 >> 5], 1u << (j0 & 31u));
+                    L.lit_shift[__popc(run_mask & ((1u << sl) - 1u))] = rel0 - lit_a;     // position - consumption index
+                }
+            }
+            wave::sync();
+            {
+                const bool rd = on && sl < kRoundMax / 32u;
+                const uint32_t w = rd ? L.start_bits[sl] : 0u, v = rd ? L.lit_bits[sl] : 0u;
+                const uint32_t cw = wave::half_scan_incl((uint32_t)__popc(w)), cv = wave::half_scan_incl((uint32_t)__popc(v));
+                if (on && sl < kRoundMax / 32u) { L.start_cum[sl] = (uint8_t)(cw - (uint32_t)__popc(w)); L.lit_cum[sl] = (uint8_t)(cv - (uint32_t)__popc(v)); }
+            }
+            wave::sync();
+            // exact dependencies of my copy piece: the pieces (of commands before me) that own bytes of my
+            // source range inside this group; everything below the group is final
+            uint32_t dep_mask = 0;
+            if (plen && src_end > gpos) {
+                const uint32_t hi_rel = src_end - 1u - gpos;
+                const uint32_t hi = L.start_cum[hi_rel >> 5] + (uint32_t)__popc(L.start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
+                uint32_t lo = 0;
+                if (psrc > gpos) {
+                    const uint32_t lo_rel = psrc - gpos;
+                    lo = L.start_cum[lo_rel >> 5] + (uint32_t)__popc(L.start_bits[lo_rel >> 5] & (0xFFFFFFFFu >> (31u - (lo_rel & 31u)))) - 1u;
+                }
+                // ranks lo .. hi-1 among the group's pieces; the pieces are consecutive commands (every
+                // command has at least one byte), so rank r is lane first_piece + r.  Only pieces before
+                // me can still be unfinished.
+                const uint32_t first_piece = ctz_u32(piece_mask);
+                const uint32_t lo_l = first_piece + lo, hi_l = min_u32(first_piece + hi, sl);
+                if (hi_l > lo_l) dep_mask = ((1u << hi_l) - 1u) & ~((1u << lo_l) - 1u);
+            }
+            clk.lap(kPhCopyFence);
+
+            // -- 4. literals of the group.  Literal j of the round comes from sub-stream j mod 32 and is
+            //       consumption index prev_tail + j (PageDecoder.cpp:196-206); indices below prev_tail were
+            //       decoded in earlier rounds and wait in the carry ring.  Each literal goes straight to its
+            //       place: the owning literal run is the number of run starts at or below it (bitmap +
+            //       popcount), and a run's literals sit at consumption index + a per-run shift.
+            if (on) {
+                const uint32_t cf0 = F0, cf1 = F1 < prev_tail ? F1 : prev_tail;        // carried part of [F0, F1)
+                for (uint32_t f = cf0 + sl; f < cf1; f += 32u) {
+                    const uint32_t idx = f - F0;
+                    const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
+                    L.win[span0 - g0 + f + L.lit_shift[run & 31u]] = L.carry[(carry_head + f) & 63u];
+                }
+                const uint32_t J1 = F1 > prev_tail ? F1 - prev_tail : 0u;
+                for (; next_j < J1; next_j += 32u) {
+                    uint32_t ll;
+                    br.ensure(15);
+                    const uint32_t lit = decode_symbol<kLutBitsLit>(t_lit, br, ll);
+                    br.consume(ll);
+                    const uint32_t idx = prev_tail + next_j - F0;
+                    const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
+                    L.win[span0 - g0 + prev_tail + next_j + L.lit_shift[run & 31u]] = (uint8_t)lit;
+                }
+            }
+            clk.lap(kPhLiterals);
+
+            // -- 5a. far sources into the staging area (aligned 8-byte LDS writes)
+            if (ft_a0) L.stage[(ft_stage >> 3) + ft_c0] = fe0;
+            if (ft_a1) L.stage[(ft_stage >> 3) + ft_c1] = fe1;
+            for (uint32_t c = ft.member + (2u << ft.log2_size); wave::any(ft.serves && far_mask && 8u * c < ft_len); c += 1u << ft.log2_size) {
+                if (ft.serves && far_mask && 8u * c < ft_len) L.stage[(ft_stage >> 3) + c] = load_u64u(job.out + ft_src + 8u * c);
+            }
+            wave::sync();
+            clk.lap(kPhLvLong);
+
+            // -- 5b. LZ77 copies in dependency levels.  A piece runs as soon as none of the pieces its
+            //        source overlaps is still unfinished (dep_mask).  Every level shares the 32 lanes among
+            //        its ready pieces (teams of 1..32 lanes), 8 bytes per lane per step; overlapping copies
+            //        replay their pattern modulo the distance, so a copy never waits for itself.  A step's
+            //        reads precede its writes (LDS is in order within the wave).
+            {
+                const uint32_t packed = plen | (far_len << 11) | ((stage_off >> 3) << 22);
+                const uint32_t src_idx = psrc - view.win_base;          // window index of the pattern start (negative when far)
+                const uint32_t dst_idx = pdst - view.win_base;
+                uint32_t todo = wave::half_ballot(plen != 0u);
+                while (wave::any(todo != 0u)) {
+                    clk.count(kPhLevels, 1);
+                    const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
+                    const uint32_t ready_mask = wave::half_ballot(ready);
+                    const Team t = make_team(ready_mask, sl);
+                    const uint32_t t_pk = wave::half_shfl(packed, t.job), t_dist = wave::half_shfl(dist, t.job);
+                    const uint32_t t_src = wave::half_shfl(src_idx, t.job), t_dst = wave::half_shfl(dst_idx, t.job);
+                    const uint32_t t_len = t_pk & 0x7FFu, t_far = (t_pk >> 11) & 0x7FFu;
+                    const uint8_t* t_stage = reinterpret_cast<const uint8_t*>(L.stage) + ((t_pk >> 22) << 3);
+                    const uint8_t* t_win = L.win + (int32_t)t_src;
+                    uint8_t* t_out = L.win + t_dst;
+                    const bool act = t.serves && ready_mask != 0u;
+                    const uint32_t t_pat = t_dist < t_len ? t_dist : t_len;
+                    const bool whole = t_far == 0u || t_far == t_pat;    // pattern in one place (window or staging area)
+                    const uint8_t* t_base = t_far ? t_stage : t_win;
+                    const bool overlap = t_dist < t_len;
+                    clk.lap(kPhLvShort);
+                    for (uint32_t c = t.member; wave::any(act && 8u * c < t_len); c += 1u << t.log2_size) {
+                        const uint32_t j = 8u * c;
+                        if (act && j < t_len) {
+                            const uint32_t r = overlap ? mod_u16(j, t_dist) : j;
+                            uint64_t v;
+                            if (whole) v = pattern_source8(t_base, t_dist, r);
+                            else {                                      // pattern straddles the window boundary: byte by byte
+                                v = 0;
+                                uint32_t rr = r;
+                                for (uint32_t b = 0; b < 8u; ++b) {
+                                    const uint32_t x = rr < t_far ? t_stage[rr] : t_win[rr];
+                                    v |= (uint64_t)x << (8u * b);
+                                    rr = rr + 1u == t_dist ? 0u : rr + 1u;
+                                }
+                            }
+                            store_bytes(t_out + j, v, t_len - j);
+                        }
+                        wave::sync();
+                    }
+                    todo &= ~ready_mask;
+                    wave::sync();
+                    clk.lap(kPhLvBytes);
+                }
+            }
+            clk.lap(kPhCopyLevels);
         }
 
-        clk.lap(kPhPositions);
-        // -- 4. literals: literal j of the round comes from sub-stream j mod 32 and is the
-        //       (prev_tail + j)-th literal the round's commands consume (PageDecoder.cpp:196-206).
-        //       Each literal goes straight to its place: in a windowed round the owning literal run is
-        //       the number of run starts at or below j (one bitmap word per step of 32 literals); in a
-        //       global-memory round the owner is found by binary search over the insert prefix sums.
+        // literals decoded beyond what the round consumes wait in the carry ring (< 32 of them)
         if (live) {
-            const uint32_t ac = litcount > prev_tail ? litcount - prev_tail : 0u;
-            const uint32_t mult = n ? (ac + n - 1u) / n : 0u;
-            const uint32_t rlit = n * mult;
             const uint32_t from_carry = min_u32(prev_tail, litcount);
             const uint32_t new_head = carry_head + from_carry;
             const uint32_t kept = prev_tail - from_carry;               // stays in the ring (only when rlit == 0)
-            // literals decoded in earlier rounds
-            if (sl < from_carry) {
-                const uint32_t f = sl;
-                uint32_t c = 0;
-                for (uint32_t s = 16; s; s >>= 1) if (L.round_ins_incl[c + s - 1u] <= f) c += s;
-                view.put(out_pos + f + L.round_copy_excl[c], L.carry[(carry_head + f) & 63u]);
-            }
-            uint32_t runs_before = 0;
-            for (uint32_t j = sl; j < rlit; j += 32u) {
+            for (; next_j < rlit; next_j += 32u) {
                 uint32_t ll;
                 br.ensure(15);
-                const uint32_t lit = decode_symbol(t_lit, br, ll);
+                const uint32_t lit = decode_symbol<kLutBitsLit>(t_lit, br, ll);
                 br.consume(ll);
-                const uint32_t f = prev_tail + j;
-                if (f >= litcount) L.carry[(new_head + kept + (f - litcount)) & 63u] = (uint8_t)lit;
-                else if (fast) {
-                    const uint32_t w = L.lit_bits[j >> 5];
-                    const uint32_t run = runs_before + (uint32_t)__popc(w & (0xFFFFFFFFu >> (31u - sl))) - 1u;
-                    L.win[span0 + f + L.lit_shift[run & 31u]] = (uint8_t)lit;
-                    runs_before += (uint32_t)__popc(w);
-                } else {
-                    uint32_t c = 0;
-                    for (uint32_t s = 16; s; s >>= 1) if (L.round_ins_incl[c + s - 1u] <= f) c += s;
-                    job.out[out_pos + f + L.round_copy_excl[c]] = (uint8_t)lit;
-                }
+                L.carry[(new_head + kept + (prev_tail + next_j - litcount)) & 63u] = (uint8_t)lit;
             }
             carry_head = new_head;
             prev_tail = rlit + prev_tail - litcount;
         }
 
-        clk.lap(kPhLiterals);
-        // -- 5a. windowed round: far copies into the staging area (aligned 8-byte LDS writes)
-        if (far_short) {
-            uint64_t* st = &L.stage[stage_off >> 3];
-            st[0] = f0;
-            if (far_len > 8u) st[1] = f1;
-            if (far_len > 16u) st[2] = f2;
-            if (far_len > 24u) st[3] = f3;
-        }
-        {
-            uint32_t long_far = wave::half_ballot(far_len > kShortCopy);
-            while (wave::any(long_far != 0u)) {                         // all 32 lanes per command
-                const uint32_t k = long_far ? ctz_u32(long_far) : 0u;
-                const uint32_t sp = wave::half_bcast(src_pos, k), cl = wave::half_bcast(far_len, k);
-                const uint32_t so = wave::half_bcast(stage_off, k);
-                if (long_far) {
-                    for (uint32_t j = 8u * sl; j < cl; j += 1024u) {
-                        uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                        v0 = load_u64u(job.out + sp + j);
-                        if (j + 256u < cl) v1 = load_u64u(job.out + sp + j + 256u);
-                        if (j + 512u < cl) v2 = load_u64u(job.out + sp + j + 512u);
-                        if (j + 768u < cl) v3 = load_u64u(job.out + sp + j + 768u);
-                        L.stage[(so + j) >> 3] = v0;
-                        if (j + 256u < cl) L.stage[(so + j + 256u) >> 3] = v1;
-                        if (j + 512u < cl) L.stage[(so + j + 512u) >> 3] = v2;
-                        if (j + 768u < cl) L.stage[(so + j + 768u) >> 3] = v3;
-                    }
-                }
-                long_far &= long_far - 1u;
-            }
-        }
-        wave::sync();
-        clk.lap(kPhCopyFence);
-        // -- 5b. windowed round: LZ77 copies, one lane per command, in dependency levels.  A copy runs
-        //        as soon as none of the commands its source overlaps is still unfinished (dep_mask);
-        //        overlapping copies read their pattern modulo the distance, so a copy never waits for
-        //        itself.  All traffic is byte-granular LDS; a level's reads precede its writes.
-        {
-            const uint8_t* stage8 = reinterpret_cast<const uint8_t*>(L.stage) + stage_off;
-            // window index of the pattern start; negative when it begins below the window, in which
-            // case only offsets >= far_len (which are inside the window) are dereferenced
-            const uint8_t* src8 = L.win + (int32_t)(src_pos - view.win_base);
-            uint8_t* dst8 = L.win + (copy_dst - view.win_base);
-            uint32_t todo = wave::half_ballot(fast && cp);
-            while (wave::any(todo != 0u)) {
-                clk.count(kPhLevels, 1);
-                const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
-                const uint32_t ready_mask = wave::half_ballot(ready);
-                // the whole pattern in one place (window or staging area): 8-byte pieces, all loads of the
-                // command before its stores; overlapping copies replay the pattern modulo the distance
-                const bool simple = far_len == 0u || far_len == pattern;
-                if (ready && copy <= kShortCopy && simple) {
-                    const uint8_t* b = far_len ? stage8 : src8;
-                    uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                    uint32_t r = 0;
-                    v0 = pattern_source8(b, dist, r);
-                    if (copy > 8u) { r = advance_mod(r, 8u, dist); v1 = pattern_source8(b, dist, r); }
-                    if (copy > 16u) { r = advance_mod(r, 8u, dist); v2 = pattern_source8(b, dist, r); }
-                    if (copy > 24u) { r = advance_mod(r, 8u, dist); v3 = pattern_source8(b, dist, r); }
-                    store_bytes(dst8, v0, copy);
-                    if (copy > 8u) store_bytes(dst8 + 8, v1, copy - 8u);
-                    if (copy > 16u) store_bytes(dst8 + 16, v2, copy - 16u);
-                    if (copy > 24u) store_bytes(dst8 + 24, v3, copy - 24u);
-                }
-                clk.lap(kPhLvShort);
-                const bool rs = ready && copy <= kShortCopy && !simple;     // overlapping or straddling: byte loop
-                // branch-free: inactive lanes read win[0] and write their sink byte, so the four reads
-                // (and then the four writes) of a step issue back to back behind a single wait
-                uint32_t r = 0;
-                for (uint32_t i = 0; wave::any(rs && i < copy); i += 4u) {
-                    const bool a0 = rs && i < copy, a1 = rs && i + 1u < copy, a2 = rs && i + 2u < copy, a3 = rs && i + 3u < copy;
-                    const uint8_t* p0 = a0 ? (r < far_len ? stage8 : src8) + r : L.win; r = r + 1u == dist ? 0u : r + 1u;
-                    const uint8_t* p1 = a1 ? (r < far_len ? stage8 : src8) + r : L.win; r = r + 1u == dist ? 0u : r + 1u;
-                    const uint8_t* p2 = a2 ? (r < far_len ? stage8 : src8) + r : L.win; r = r + 1u == dist ? 0u : r + 1u;
-                    const uint8_t* p3 = a3 ? (r < far_len ? stage8 : src8) + r : L.win; r = r + 1u == dist ? 0u : r + 1u;
-                    const uint8_t b0 = *p0, b1 = *p1, b2 = *p2, b3 = *p3;
-                    wave::sync();
-                    uint8_t* sink = &L.sink[sl];
-                    *(a0 ? dst8 + i : sink) = b0;
-                    *(a1 ? dst8 + i + 1u : sink) = b1;
-                    *(a2 ? dst8 + i + 2u : sink) = b2;
-                    *(a3 ? dst8 + i + 3u : sink) = b3;
-                }
-                clk.lap(kPhLvBytes);
-                uint32_t long_mask = wave::half_ballot(ready && copy > kShortCopy);
-                while (wave::any(long_mask != 0u)) {                    // all 32 lanes per command, 4 bytes per lane per step
-                    const uint32_t k = long_mask ? ctz_u32(long_mask) : 0u;
-                    const uint32_t k_src = wave::half_bcast(src_pos - view.win_base, k), k_dst = wave::half_bcast(copy_dst - view.win_base, k);
-                    const uint32_t k_dist = wave::half_bcast(dist, k), k_len = wave::half_bcast(copy, k);
-                    const uint32_t k_far = wave::half_bcast(far_len, k), k_stage = wave::half_bcast(stage_off, k);
-                    const uint8_t* kst = reinterpret_cast<const uint8_t*>(L.stage) + k_stage;
-                    const uint8_t* ksrc = L.win + (int32_t)k_src;
-                    uint8_t* kdst = L.win + k_dst;
-                    const bool on = long_mask != 0u;
-                    const bool overlap = on && k_dist < k_len;
-                    const uint32_t k_pat = k_dist < k_len ? k_dist : k_len;
-                    const bool k_simple = k_far == 0u || k_far == k_pat;
-                    if (on && k_simple) {                               // 8 bytes per lane per step, four steps in flight
-                        const uint8_t* b = k_far ? kst : ksrc;
-                        uint32_t r8 = overlap ? (8u * sl) % k_dist : 8u * sl;
-                        const uint32_t step8 = overlap ? 256u % k_dist : 256u;
-                        for (uint32_t j = 8u * sl; j < k_len; j += 1024u) {
-                            uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                            v0 = pattern_source8(b, k_dist, r8); r8 = overlap ? advance_mod(r8, step8, k_dist) : r8 + 256u;
-                            if (j + 256u < k_len) { v1 = pattern_source8(b, k_dist, r8); r8 = overlap ? advance_mod(r8, step8, k_dist) : r8 + 256u; }
-                            if (j + 512u < k_len) { v2 = pattern_source8(b, k_dist, r8); r8 = overlap ? advance_mod(r8, step8, k_dist) : r8 + 256u; }
-                            if (j + 768u < k_len) { v3 = pattern_source8(b, k_dist, r8); r8 = overlap ? advance_mod(r8, step8, k_dist) : r8 + 256u; }
-                            store_bytes(kdst + j, v0, k_len - j);
-                            if (j + 256u < k_len) store_bytes(kdst + j + 256u, v1, k_len - j - 256u);
-                            if (j + 512u < k_len) store_bytes(kdst + j + 512u, v2, k_len - j - 512u);
-                            if (j + 768u < k_len) store_bytes(kdst + j + 768u, v3, k_len - j - 768u);
-                        }
-                    }
-                    const bool bytewise = on && !k_simple;              // pattern straddles the window boundary
-                    // lane handles bytes sl, sl + 32, ...; r follows j modulo the distance
-                    uint32_t rl = overlap ? sl % k_dist : sl;
-                    const uint32_t step = overlap ? 32u % k_dist : 32u;
-                    for (uint32_t j0 = 0; wave::any(bytewise && j0 < k_len); j0 += 128u) {
-                        const uint32_t j = j0 + sl;
-                        const bool a0 = bytewise && j < k_len, a1 = bytewise && j + 32u < k_len, a2 = bytewise && j + 64u < k_len, a3 = bytewise && j + 96u < k_len;
-                        const uint8_t* p0 = a0 ? (rl < k_far ? kst : ksrc) + rl : L.win; rl = overlap ? advance_mod(rl, step, k_dist) : rl + 32u;
-                        const uint8_t* p1 = a1 ? (rl < k_far ? kst : ksrc) + rl : L.win; rl = overlap ? advance_mod(rl, step, k_dist) : rl + 32u;
-                        const uint8_t* p2 = a2 ? (rl < k_far ? kst : ksrc) + rl : L.win; rl = overlap ? advance_mod(rl, step, k_dist) : rl + 32u;
-                        const uint8_t* p3 = a3 ? (rl < k_far ? kst : ksrc) + rl : L.win; rl = overlap ? advance_mod(rl, step, k_dist) : rl + 32u;
-                        const uint8_t b0 = *p0, b1 = *p1, b2 = *p2, b3 = *p3;
-                        wave::sync();
-                        uint8_t* sink = &L.sink[sl];
-                        *(a0 ? kdst + j : sink) = b0;
-                        *(a1 ? kdst + j + 32u : sink) = b1;
-                        *(a2 ? kdst + j + 64u : sink) = b2;
-                        *(a3 ? kdst + j + 96u : sink) = b3;
-                    }
-                    long_mask &= long_mask - 1u;
-                }
-                todo &= ~ready_mask;
-                wave::sync();
-                clk.lap(kPhLvLong);
-            }
-        }
-        clk.lap(kPhCopyLevels);
-
-        // -- 5c. round in global memory (more than kRoundMax bytes): LZ77 copies in dependency levels.
-        //        A copy is ready once its source range ends at or below the destination of the first
-        //        unfinished copy; overlapping sources are read modulo the distance, so a copy never
-        //        depends on itself.  Each level's stores are performed before the next level loads.
-        uint32_t todo = wave::half_ballot(slow && cp);
-        if (wave::any(slow)) wave::global_fence();                      // literals just stored, window just flushed
-        while (wave::any(todo != 0u)) {
-            const uint32_t first_dst = wave::half_bcast(copy_dst, todo ? ctz_u32(todo) : 0u);
-            const bool mine = ((todo >> sl) & 1u) != 0u;
-            const bool ready = mine && src_end <= first_dst;
-            const uint32_t ready_mask = wave::half_ballot(ready);
-            uint32_t long_mask = wave::half_ballot(ready && copy > kShortCopy);
-            if (ready && copy <= kShortCopy) {                          // one lane per command, <= 4 chunks of 8 bytes
-                uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                uint32_t r = 0;
-                v0 = copy_source8(view, src_pos, dist, r);
-                if (copy > 8u) { r = advance_mod(r, 8u, dist); v1 = copy_source8(view, src_pos, dist, r); }
-                if (copy > 16u) { r = advance_mod(r, 8u, dist); v2 = copy_source8(view, src_pos, dist, r); }
-                if (copy > 24u) { r = advance_mod(r, 8u, dist); v3 = copy_source8(view, src_pos, dist, r); }
-                view.write(copy_dst, v0, copy);
-                if (copy > 8u) view.write(copy_dst + 8u, v1, copy - 8u);
-                if (copy > 16u) view.write(copy_dst + 16u, v2, copy - 16u);
-                if (copy > 24u) view.write(copy_dst + 24u, v3, copy - 24u);
-            }
-            while (wave::any(long_mask != 0u)) {                        // all 32 lanes per command, 8 bytes per lane per step
-                const uint32_t k = long_mask ? ctz_u32(long_mask) : 0u;
-                const uint32_t cd = wave::half_bcast(copy_dst, k), dd = wave::half_bcast(dist, k);
-                const uint32_t cl = wave::half_bcast(copy, k);
-                if (long_mask) {
-                    const uint32_t sp = cd - dd;
-                    const bool overlap = dd < cl;
-                    uint32_t r = overlap ? (8u * sl) % dd : 8u * sl;
-                    const uint32_t step = overlap ? 256u % dd : 256u;
-                    for (uint32_t j = 8u * sl; j < cl; j += 1024u) {    // up to four chunks in flight per lane
-                        uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                        v0 = copy_source8(view, sp, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u;
-                        if (j + 256u < cl) { v1 = copy_source8(view, sp, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
-                        if (j + 512u < cl) { v2 = copy_source8(view, sp, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
-                        if (j + 768u < cl) { v3 = copy_source8(view, sp, dd, r); r = overlap ? advance_mod(r, step, dd) : r + 256u; }
-                        view.write(cd + j, v0, cl - j);
-                        if (j + 256u < cl) view.write(cd + j + 256u, v1, cl - j - 256u);
-                        if (j + 512u < cl) view.write(cd + j + 512u, v2, cl - j - 512u);
-                        if (j + 768u < cl) view.write(cd + j + 768u, v3, cl - j - 768u);
-                    }
-                }
-                long_mask &= long_mask - 1u;
-            }
-            todo &= ~ready_mask;
-            if (wave::any(todo != 0u)) wave::global_fence();
-        }
-        if (slow) {                                                     // the window restarts empty after a global round
-            flushed = out_pos + round_bytes;
-            view.valid_from = flushed;
-            view.win_base = flushed & ~15u;
-        }
-
-        clk.lap(kPhSlow);
         out_pos += round_bytes;
         if (sent_mask) live = false;
     }
 
     wave::sync();
     if (wave::any(windowed)) {
-        view.use_win = true;
         if (windowed) flushed = flush_window(view, flushed, out_pos, true, sl);
     }
     if (job.valid && !stored && out_pos != job.out_size) bad = true;      // a valid page fills its output exactly

@@ -91,6 +91,7 @@ inline uint32_t __brev(uint32_t x)
     x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
     return __builtin_bswap32(x);
 }
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline uint32_t atomicAdd(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 inline uint32_t atomicOr(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }

@@ -14,7 +14,7 @@ def compose(seed, n):
     out = np.empty(n + 70000, np.uint8)
     pos = 0
     while pos < n:
-        kind = rng.integers(0, 7)
+        kind = rng.integers(0, 8)
         if kind == 0 or pos < 16:                                   # fresh literals
             k = int(rng.integers(1, 200))
             out[pos:pos + k] = rng.integers(0, 256, k, dtype=np.uint8)
@@ -35,6 +35,9 @@ def compose(seed, n):
         elif kind == 5:                                             # far repeat, long
             d = int(rng.integers(1, pos + 1)); k = int(min(rng.integers(40, 4000), d))
             out[pos:pos + k] = out[pos - d:pos - d + k]
+        elif kind == 7:                                             # long literal stretch (crosses assembly groups)
+            k = int(rng.integers(500, 5000))
+            out[pos:pos + k] = rng.integers(0, 256, k, dtype=np.uint8)
         else:                                                       # skewed literals
             k = int(rng.integers(1, 400))
             out[pos:pos + k] = np.minimum(rng.geometric(0.3, k) - 1, 255)
