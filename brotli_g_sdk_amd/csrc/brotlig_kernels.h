@@ -85,17 +85,17 @@ template <> struct PhaseClock<true> {
 };
 
 // ---- tunables ---------------------------------------------------------------------------
-constexpr int kLutBitsIcp = 9;
-constexpr int kLutBitsDist = 9;
-constexpr int kLutBitsLit = 9;
+constexpr int kLutBitsIcp = 8;
+constexpr int kLutBitsDist = 8;
+constexpr int kLutBitsLit = 8;
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index
 constexpr uint32_t kShortCopy = 32;         // copies up to this length run one-lane-per-command
 // Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
 // flushed to global memory in aligned 16-byte stores when it slides.
-constexpr uint32_t kWin = 1792;
-constexpr uint32_t kHist = 896;             // history kept across a slide (>= kWin / 2: see the slide below)
+constexpr uint32_t kWin = 1280;
+constexpr uint32_t kHist = 640;             // history kept across a slide (>= kWin / 2: see the slide below)
 constexpr uint32_t kRoundMax = kWin - kHist;
 constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
 
@@ -119,61 +119,84 @@ __device__ static const uint8_t kCodeLenOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16
 
 // ---- LDS layout: one of these per 32-lane half ---------------------------------------------
 struct __attribute__((aligned(16))) PageLds {
+    // decode LUTs, then the staging area: while a table is being built its LUT and the 1 KiB behind it
+    // serve as scratch (code-length LUT, counting-sort counters), so the order of these four matters --
+    // ICP borrows the distance LUT, distance borrows the literal LUT, literal borrows the staging area,
+    // each of which is still (or again) free at that point.
     uint16_t lut_icp[1 << kLutBitsIcp];
     uint16_t lut_dist[1 << kLutBitsDist];
     uint16_t lut_lit[1 << kLutBitsLit];
-    uint16_t sorted_icp[kIcpAlphabet];
-    uint16_t sorted_dist[kDistAlphabet];
-    uint16_t sorted_lit[kLitAlphabet];
+    uint64_t stage[kStageBytes / 8];        // per group: source bytes of far copies (older than the window)
+    uint32_t sorted_icp[(kIcpAlphabet + 2) / 3];       // symbols in canonical-code order, three 10-bit fields per word
+    uint32_t sorted_dist[(kDistAlphabet + 2) / 3];
+    uint32_t sorted_lit[(kLitAlphabet + 2) / 3];
     uint16_t limit[3][16] __attribute__((aligned(16)));     // per code length: exclusive upper bound, left-justified to 15 bits
     uint32_t first_offs[3][16]; // per code length: first code (left-justified) | index of its first symbol in sorted_* << 16
     uint32_t start_bits[kRoundMax / 32];    // per group: bit p set <=> a command's piece starts at group byte p
     uint32_t lit_bits[kRoundMax / 32];      // per group: bit i set <=> the group's i-th literal starts a literal run
+    uint32_t lit_shift[32];                 // per group: (round-relative position - consumption index) of the r-th run
     uint8_t  start_cum[kRoundMax / 32];     // per group: piece starts in earlier words of start_bits
     uint8_t  lit_cum[kRoundMax / 32];       // per group: run starts in earlier words of lit_bits
-    uint32_t lit_shift[32];                 // per group: (round-relative position - consumption index) of the r-th run
-    uint64_t stage[kStageBytes / 8];        // per round: source bytes of far copies (older than the window)
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
     uint8_t  sink[64];              // write target of inactive lanes in branch-free copy loops
     uint8_t  win[kWin + 48] __attribute__((aligned(16)));   // output window; doubles as the code-length
                                                              // scratch (728 B) while tables are built
 };
+constexpr uint32_t kTableScratchBytes = 1024;   // 512-entry code-length LUT, or 16 x 32 counters, as uint16
+static_assert(sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist)) >= kTableScratchBytes, "ICP build scratch");
+static_assert(sizeof(uint16_t) * ((1 << kLutBitsDist) + (1 << kLutBitsLit)) >= kTableScratchBytes, "distance build scratch");
+static_assert(sizeof(uint16_t) * (1 << kLutBitsLit) + kStageBytes >= kTableScratchBytes, "literal build scratch");
+static_assert(__builtin_offsetof(PageLds, lut_dist) == sizeof(uint16_t) * (1 << kLutBitsIcp), "LUTs must be contiguous");
+static_assert(__builtin_offsetof(PageLds, stage) == sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)), "staging area must follow the LUTs");
+static_assert(kWin + 48 >= kIcpAlphabet, "the window holds the code lengths during the table build");
 
 struct __attribute__((aligned(16))) WaveLds {
     PageLds  page[2];
     uint32_t len_code_tab[48];
 };
 
+__device__ __forceinline__ uint64_t load_u64u_g(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
 // ---- per-lane bit reader over one sub-bitstream ---------------------------------------------
-// LSB-first.  `buf` holds `avail` valid bits; `nextw` is the dword after them, already in flight.
+// LSB-first.  `buf` holds `avail` valid bits.  Behind it sit 64 queued bits (`queue`, `queued` of them
+// still unread) and 64 bits in flight from global memory (`flight`): a refill takes 32 queued bits,
+// and only every second refill touches the in-flight pair -- loaded at least two refills earlier --
+// and issues the next 8-byte load.  Loads are 8 bytes at 4-byte aligned offsets.
 struct BitReader {
     const uint8_t* base;    // page start in the input buffer
     uint32_t limit;         // bytes readable from base (reads beyond return 0)
     uint64_t buf;
     uint32_t avail;
-    uint32_t next;          // byte offset of nextw, dword aligned relative to base
-    uint32_t nextw;
+    uint32_t next;          // byte offset of the next 8-byte load, dword aligned relative to base
+    uint64_t queue;
+    uint32_t queued;        // 0, 32 or 64
+    uint64_t flight;
 
-    __device__ __forceinline__ uint32_t load(uint32_t rel) const
+    __device__ __forceinline__ uint64_t load8(uint32_t rel) const
     {
-        return rel < limit ? *reinterpret_cast<const uint32_t*>(base + rel) : 0u;
+        if (rel + 8u <= limit) return load_u64u_g(base + rel);
+        uint64_t v = 0;
+        if (rel < limit) v = *reinterpret_cast<const uint32_t*>(base + rel);       // limit is a multiple of 4
+        return v;
     }
     __device__ __forceinline__ void init(const uint8_t* b, uint32_t lim, uint32_t start)
     {
         base = b; limit = lim;
         const uint32_t a = start & ~3u, skip = (start & 3u) * 8u;
-        buf = (uint64_t)(load(a) >> skip);
+        const uint64_t first = load8(a);
+        buf = (uint64_t)((uint32_t)first >> skip);
         avail = 32u - skip;
-        next = a + 4u;
-        nextw = load(next);
+        queue = first >> 32; queued = 32u;
+        next = a + 8u;
+        flight = load8(next); next += 8u;
         if (avail < 32u) refill();
     }
     __device__ __forceinline__ void refill()
     {
-        buf |= (uint64_t)nextw << avail;
+        if (queued == 0u) { queue = flight; queued = 64u; flight = load8(next); next += 8u; }
+        buf |= (uint64_t)(uint32_t)queue << avail;
+        queue >>= 32; queued -= 32u;
         avail += 32u;
-        next += 4u;
-        nextw = load(next);
     }
     __device__ __forceinline__ void ensure(uint32_t n) { if (avail < n) refill(); }          // n <= 32
     __device__ __forceinline__ uint32_t peek(uint32_t n) const                               // n <= 32
@@ -296,9 +319,21 @@ __device__ __forceinline__ uint32_t advance_mod(uint32_t r, uint32_t step, uint3
 
 // One prefix-code table: which LDS arrays it lives in.
 struct TableRef {
-    uint16_t* lut; uint16_t* sorted; uint16_t* limit; uint32_t* first_offs;
+    uint16_t* lut; uint32_t* sorted; uint16_t* limit; uint32_t* first_offs;
     uint32_t alphabet; int lut_bits;
 };
+
+// sorted-symbol arrays: element i lives in bits [10 * (i % 3), +10) of word i / 3
+__device__ __forceinline__ uint32_t sorted_get(const uint32_t* words, uint32_t i)
+{
+    const uint32_t w = (i * 43691u) >> 17;                      // i / 3 for i < 98304
+    return (words[w] >> (10u * (i - 3u * w))) & 0x3FFu;
+}
+__device__ __forceinline__ void sorted_put(uint32_t* words, uint32_t i, uint32_t sym)    // words pre-zeroed
+{
+    const uint32_t w = (i * 43691u) >> 17;
+    atomicOr(&words[w], sym << (10u * (i - 3u * w)));
+}
 
 // Decode one symbol from `br` (needs avail >= 15 on entry).  Returns symbol, sets len.
 // kBits = index width of the table's primary LUT.  Codes longer than that take the canonical route:
@@ -326,7 +361,7 @@ __device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitRe
     uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
     idx = min_u32(idx, t.alphabet - 1u);
     len = l;
-    return t.sorted[idx];
+    return sorted_get(t.sorted, idx);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -420,6 +455,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         const uint32_t blk = (A + 31u) / 32u;
         const uint32_t b0 = sl * blk, b1 = min_u32(A, b0 + blk);
         if (is_complex) for (uint32_t l = 0; l < 16u; ++l) cnt[l * 32u + sl] = 0;
+        if (is_complex) for (uint32_t w = sl; w < (A + 2u) / 3u; w += 32u) t.sorted[w] = 0u;
         wave::sync();
         if (is_complex)
             for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = L.win[s] & 15u; if (l) cnt[l * 32u + sl]++; }
@@ -441,7 +477,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         if (is_complex)
             for (uint32_t s = b0; s < b1; ++s) {
                 const uint32_t l = L.win[s] & 15u;
-                if (l) { const uint32_t p = cnt[l * 32u + sl]++; t.sorted[min_u32(p, A - 1u)] = (uint16_t)s; }
+                if (l) { const uint32_t p = cnt[l * 32u + sl]++; sorted_put(t.sorted, min_u32(p, A - 1u), s); }
             }
         wave::sync();
         // primary LUT, one entry per lane per step
@@ -455,7 +491,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
                     const uint32_t fo = t.first_offs[l];
                     uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
                     idx = min_u32(idx, A - 1u);
-                    entry = ((uint32_t)t.sorted[idx] << 4) | l;
+                    entry = (sorted_get(t.sorted, idx) << 4) | l;
                 }
                 t.lut[e] = (uint16_t)entry;
             }
@@ -518,7 +554,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
     uint32_t npostfix = 0, ndirect = 0;
     bool is_delta = false;
     BitReader br;
-    br.base = job.in; br.limit = 0; br.buf = 0; br.avail = 64; br.next = 0; br.nextw = 0;
+    br.base = job.in; br.limit = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0;
     {
         uint32_t my_len = 0, hdr_bytes = 0;
         if (live) {
@@ -682,6 +718,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
         // contributes a piece to each group; a copy piece past the first is an ordinary copy from
         // `dist` bytes back (its earlier bytes are final by then).
         const uint32_t ngroups = live ? (round_bytes + kRoundMax - 1u) / kRoundMax : 0u;
+        const bool multi_group = wave::any(ngroups > 1u);
         for (uint32_t g = 0; wave::any(g < ngroups); ++g) {
             const bool on = g < ngroups;
             const uint32_t g0 = g * kRoundMax, g1 = on ? min_u32(round_bytes, g0 + kRoundMax) : g0;
@@ -728,21 +765,34 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             const uint32_t stage_len = (far_len + 7u) & ~7u;
             const uint32_t stage_incl = wave::half_scan_incl(stage_len);
             const uint32_t stage_off = stage_incl - stage_len;          // 8-byte aligned offset into L.stage
-            // team loads: every far piece gets a team of lanes; each lane fetches up to two 8-byte chunks
-            // now (consumed after the literal decode), the rare remainder later
+            // far loads are issued now and consumed after the literal decode.  Usual case (no far piece
+            // longer than 32 bytes): each lane fetches its own piece, up to four 8-byte chunks.  Otherwise
+            // every far piece gets a team of lanes, two chunks per lane now and the remainder later.
             const uint32_t far_mask = wave::half_ballot(far_len != 0u);
-            const Team ft = make_team(far_mask, sl);
-            const uint32_t ft_src = wave::half_shfl(psrc, ft.job), ft_len = wave::half_shfl(far_len, ft.job);
-            const uint32_t ft_stage = wave::half_shfl(stage_off, ft.job);
-            const uint32_t ft_c0 = ft.member, ft_c1 = ft.member + (1u << ft.log2_size);
-            const bool ft_a0 = ft.serves && far_mask && 8u * ft_c0 < ft_len, ft_a1 = ft.serves && far_mask && 8u * ft_c1 < ft_len;
-            uint64_t fe0 = 0, fe1 = 0;
-            if (ft_a0) fe0 = load_u64u(job.out + ft_src + 8u * ft_c0);
-            if (ft_a1) fe1 = load_u64u(job.out + ft_src + 8u * ft_c1);
+            const bool far_teams = wave::any(far_len > kShortCopy);
+            uint64_t fe0 = 0, fe1 = 0, fe2 = 0, fe3 = 0;
+            Team ft{5u, 0u, 0u, false};
+            uint32_t ft_src = 0, ft_len = 0, ft_stage = 0;
+            if (!far_teams) {
+                if (far_len) {
+                    const uint8_t* s8 = job.out + psrc;
+                    fe0 = load_u64u(s8);
+                    if (far_len > 8u) fe1 = load_u64u(s8 + 8);
+                    if (far_len > 16u) fe2 = load_u64u(s8 + 16);
+                    if (far_len > 24u) fe3 = load_u64u(s8 + 24);
+                }
+            } else {
+                ft = make_team(far_mask, sl);
+                ft_src = wave::half_shfl(psrc, ft.job); ft_len = wave::half_shfl(far_len, ft.job);
+                ft_stage = wave::half_shfl(stage_off, ft.job);
+                ft.serves = ft.serves && far_mask != 0u;
+                if (ft.serves && 8u * ft.member < ft_len) fe0 = load_u64u(job.out + ft_src + 8u * ft.member);
+                if (ft.serves && 8u * (ft.member + (1u << ft.log2_size)) < ft_len) fe1 = load_u64u(job.out + ft_src + 8u * (ft.member + (1u << ft.log2_size)));
+            }
             // literals of the group: consumption indices [F0, F1)
             const uint32_t mine_before = (on && ok_cmd) ? (cs <= g0 ? ins : (rel0 < g0 ? g0 - rel0 : 0u)) : 0u;   // my literals before g0
-            const uint32_t F0 = wave::half_sum(mine_before);
-            const uint32_t F1 = F0 + wave::half_sum(nlit);
+            uint32_t F0 = 0, F1 = litcount;                             // single group: all of the round's literals
+            if (multi_group) { F0 = wave::half_sum(mine_before); F1 = F0 + wave::half_sum(nlit); }
             const uint32_t run_mask = wave::half_ballot(nlit != 0u);
             const uint32_t piece_mask = wave::half_ballot(in_group);
             if (on && sl < kRoundMax / 32u) {
@@ -813,10 +863,21 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             clk.lap(kPhLiterals);
 
             // -- 5a. far sources into the staging area (aligned 8-byte LDS writes)
-            if (ft_a0) L.stage[(ft_stage >> 3) + ft_c0] = fe0;
-            if (ft_a1) L.stage[(ft_stage >> 3) + ft_c1] = fe1;
-            for (uint32_t c = ft.member + (2u << ft.log2_size); wave::any(ft.serves && far_mask && 8u * c < ft_len); c += 1u << ft.log2_size) {
-                if (ft.serves && far_mask && 8u * c < ft_len) L.stage[(ft_stage >> 3) + c] = load_u64u(job.out + ft_src + 8u * c);
+            if (!far_teams) {
+                if (far_len) {
+                    uint64_t* st = &L.stage[stage_off >> 3];
+                    st[0] = fe0;
+                    if (far_len > 8u) st[1] = fe1;
+                    if (far_len > 16u) st[2] = fe2;
+                    if (far_len > 24u) st[3] = fe3;
+                }
+            } else {
+                const uint32_t tsz = 1u << ft.log2_size;
+                if (ft.serves && 8u * ft.member < ft_len) L.stage[(ft_stage >> 3) + ft.member] = fe0;
+                if (ft.serves && 8u * (ft.member + tsz) < ft_len) L.stage[(ft_stage >> 3) + ft.member + tsz] = fe1;
+                for (uint32_t c = ft.member + 2u * tsz; wave::any(ft.serves && 8u * c < ft_len); c += tsz) {
+                    if (ft.serves && 8u * c < ft_len) L.stage[(ft_stage >> 3) + c] = load_u64u(job.out + ft_src + 8u * c);
+                }
             }
             wave::sync();
             clk.lap(kPhLvLong);
@@ -835,6 +896,37 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
                     clk.count(kPhLevels, 1);
                     const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
                     const uint32_t ready_mask = wave::half_ballot(ready);
+                    if (!wave::any(ready && plen > kShortCopy)) {
+                        // no long piece in this level: every ready lane copies its own piece, <= 4 chunks of
+                        // 8 bytes, all loads before the stores
+                        if (ready) {
+                            const uint8_t* own_stage = reinterpret_cast<const uint8_t*>(L.stage) + stage_off;
+                            const uint8_t* own_win = L.win + (int32_t)src_idx;
+                            uint8_t* own_out = L.win + dst_idx;
+                            uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+                            if (far_len == 0u || far_len == pattern) {
+                                const uint8_t* b = far_len ? own_stage : own_win;
+                                uint32_t r = 0;
+                                v0 = pattern_source8(b, dist, r);
+                                if (plen > 8u) { r = advance_mod(r, 8u, dist); v1 = pattern_source8(b, dist, r); }
+                                if (plen > 16u) { r = advance_mod(r, 8u, dist); v2 = pattern_source8(b, dist, r); }
+                                if (plen > 24u) { r = advance_mod(r, 8u, dist); v3 = pattern_source8(b, dist, r); }
+                            } else {                                    // pattern straddles the window boundary
+                                uint32_t rr = 0;
+                                for (uint32_t b = 0; b < 32u && b < plen; ++b) {
+                                    const uint64_t x = rr < far_len ? own_stage[rr] : own_win[rr];
+                                    if (b < 8u) v0 |= x << (8u * b); else if (b < 16u) v1 |= x << (8u * (b - 8u));
+                                    else if (b < 24u) v2 |= x << (8u * (b - 16u)); else v3 |= x << (8u * (b - 24u));
+                                    rr = rr + 1u == dist ? 0u : rr + 1u;
+                                }
+                            }
+                            store_bytes(own_out, v0, plen);
+                            if (plen > 8u) store_bytes(own_out + 8, v1, plen - 8u);
+                            if (plen > 16u) store_bytes(own_out + 16, v2, plen - 16u);
+                            if (plen > 24u) store_bytes(own_out + 24, v3, plen - 24u);
+                        }
+                        clk.lap(kPhLvShort);
+                    } else {
                     const Team t = make_team(ready_mask, sl);
                     const uint32_t t_pk = wave::half_shfl(packed, t.job), t_dist = wave::half_shfl(dist, t.job);
                     const uint32_t t_src = wave::half_shfl(src_idx, t.job), t_dst = wave::half_shfl(dst_idx, t.job);
@@ -851,7 +943,8 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
                     for (uint32_t c = t.member; wave::any(act && 8u * c < t_len); c += 1u << t.log2_size) {
                         const uint32_t j = 8u * c;
                         if (act && j < t_len) {
-                            const uint32_t r = overlap ? mod_u16(j, t_dist) : j;
+                            uint32_t r = j;
+                            if (overlap) r = mod_u16(j, t_dist);
                             uint64_t v;
                             if (whole) v = pattern_source8(t_base, t_dist, r);
                             else {                                      // pattern straddles the window boundary: byte by byte
@@ -867,9 +960,10 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
                         }
                         wave::sync();
                     }
+                    clk.lap(kPhLvBytes);
+                    }
                     todo &= ~ready_mask;
                     wave::sync();
-                    clk.lap(kPhLvBytes);
                 }
             }
             clk.lap(kPhCopyLevels);
@@ -1108,9 +1202,9 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
     }
 }
 
-__global__ void __launch_bounds__(64) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }
+__global__ void __launch_bounds__(64, 3) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }
 // Diagnostics twin: same code with s_memtime phase timers (BrotligDecodePhaseProfile).
-__global__ void __launch_bounds__(64) brotlig_decode_kernel_timed(DecodeArgs a) { decode_kernel_body<true>(a); }
+__global__ void __launch_bounds__(64, 3) brotlig_decode_kernel_timed(DecodeArgs a) { decode_kernel_body<true>(a); }
 
 // Device self-test of the cross-lane primitives (results checked on the host).
 __global__ void __launch_bounds__(64) brotlig_selftest_kernel(uint32_t* out)
