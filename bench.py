@@ -28,11 +28,35 @@ HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PAGE = 65536
 
 
+BC3_BLOCKS = 1024          # config 4: BC3 texture of 1024 x 1024 blocks = 16 MiB = 256 pages
+
+
+def build_bc3_streams(indices, distinct):
+    """BASELINE.json configs[3]: BC3 16-byte-block textures (the reference has no BC7: formats are
+    BC1..BC5, inc/common/BrotligCommon.h:76-83), swizzle + delta on; `distinct` different textures,
+    whole streams repeated (pre-conditioned pages are tied to their stream, so streams are tiled,
+    not pages).  Returns (streams, expected) with expected[k] = the texture bytes of stream k."""
+    from brotli_g_sdk_amd import datagen as D, encoder as E
+    pre = dict(format=3, width_blocks=BC3_BLOCKS, height_blocks=BC3_BLOCKS, swizzle=1, delta=1)
+    made = {}
+    streams, expected = [], []
+    for g in indices:
+        key = g % distinct
+        if key not in made:
+            tex = D.bc_texture(3, BC3_BLOCKS, BC3_BLOCKS, seed=key)
+            made[key] = (E.encode(tex, precondition=pre), tex)
+        streams.append(made[key][0])
+        expected.append(made[key][1])
+    return streams, expected
+
+
 def build_streams(kind, indices, pages_per_stream, distinct):
     """Builds the streams with the given global indices (the seed of a stream is its index).
     Returns (streams, expected_distinct) where expected_distinct[k] is the decompressed bytes of
     the `distinct` pages stream k is tiled from."""
     from brotli_g_sdk_amd import datagen as D, encoder as E
+    if kind == "bc3":
+        return build_bc3_streams(indices, max(1, min(distinct, 8)))
     streams, expected = [], []
     for seed in indices:
         if kind == "mixed":
@@ -95,7 +119,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="mixed", choices=["mixed", "runs", "text", "records", "samples16"])
+    ap.add_argument("--workload", default="mixed", choices=["mixed", "runs", "text", "records", "samples16", "bc3"])
     ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--pages-per-stream", type=int, default=4096)
     ap.add_argument("--distinct", type=int, default=256, help="distinct encoded pages per stream (tiled)")
@@ -120,7 +144,7 @@ def main():
     from brotli_g_sdk_amd import shard
     mine = shard.stream_indices(args.streams * world, world, rank)     # static contiguous shard of the stream list
     streams, expected = build_streams(args.workload, mine, args.pages_per_stream, distinct)
-    dec = api.BatchDecoder(streams, device=dev)
+    dec = api.BatchDecoder(streams, device=dev, out_sizes=[len(e) for e in expected] if args.workload == "bc3" else None)
 
     def barrier():
         if world > 1:
@@ -145,7 +169,7 @@ def main():
     ok = True
     for k in range(len(streams)):
         exp = torch.from_numpy(expected[k]).to(dev)
-        got = dec.d_out[dec.out_offs[k]:dec.out_offs[k] + dec.sizes[k]].view(-1, exp.numel())
+        got = dec.d_out[dec.out_offs[k]:dec.out_offs[k] + dec.sizes[k]].view(-1, exp.numel())     # tiled streams: every repeat
         ok = ok and bool((got == exp.unsqueeze(0)).all())
     if world > 1:
         import torch.distributed as dist
@@ -174,10 +198,14 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "bit_exact": ok,
-            "config": {"workload": f"{args.streams} streams x {args.pages_per_stream} pages x 64 KiB per GPU "
-                                   f"({per_rank_u / 2**30:.2f} GiB), '{args.workload}' synthetic "
-                                   f"(BASELINE.json configs[2] when mixed), {distinct} distinct encoded pages per stream "
-                                   f"tiled, compression ratio {per_rank_u / per_rank_c:.2f}",
+            "config": {"workload": (f"{args.streams} streams x {args.pages_per_stream} pages x 64 KiB per GPU "
+                                    f"({per_rank_u / 2**30:.2f} GiB), '{args.workload}' synthetic "
+                                    f"(BASELINE.json configs[2] when mixed), {distinct} distinct encoded pages per stream "
+                                    f"tiled, compression ratio {per_rank_u / per_rank_c:.2f}") if args.workload != "bc3" else
+                                   (f"{args.streams} BC3 textures of {BC3_BLOCKS}x{BC3_BLOCKS} blocks (16 MiB, 256 pages each, "
+                                    f"{per_rank_u / 2**30:.2f} GiB per GPU), swizzle + delta pre-conditioning, "
+                                    f"{max(1, min(distinct, 8))} distinct textures repeated (BASELINE.json configs[3]; BC7 is not a "
+                                    f"reference format, BC3 stands in), compression ratio {per_rank_u / per_rank_c:.2f}"),
                        "sharding": "independent streams per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,

@@ -36,6 +36,9 @@ def hip_sources():
 
 
 def build_hip(force=False):
+    override = os.environ.get("BROTLIG_HIP_SO")     # diagnostics: load an alternative build of the library
+    if override:
+        return override
     src = hip_sources()
     if force or _stale(HIP_SO, src):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
