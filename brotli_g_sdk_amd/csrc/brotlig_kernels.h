@@ -250,11 +250,14 @@ __device__ __forceinline__ uint64_t pattern_source8(const uint8_t* s, uint32_t d
         const uint64_t lo = load_u64u(s + r), hi = load_u64u(s);
         return (lo & ((1ull << (8u * n)) - 1ull)) | (hi << (8u * n));
     }
-    const uint64_t p = load_u64u(s);
-    uint64_t v = 0;
-    uint32_t idx = r;
-    for (uint32_t k = 0; k < 8u; ++k) { v |= ((p >> (8u * idx)) & 0xFFull) << (8u * k); if (++idx == d) idx = 0; }
-    return v;
+    // d < 8: rotate the d-byte period so that it starts at offset r, then double it up to 8 bytes
+    const uint32_t db = 8u * d;
+    const uint64_t p = load_u64u(s) & ((1ull << db) - 1ull);
+    uint64_t q = r ? ((p >> (8u * r)) | (p << (8u * (d - r)))) & ((1ull << db) - 1ull) : p;
+    q |= q << db;                                                   // 2 periods
+    if (2u * db < 64u) q |= q << (2u * db);                          // 4 periods
+    if (4u * db < 64u) q |= q << (4u * db);                          // 8 periods
+    return q;
 }
 // Position of the q-th (0-based) set bit of m; q < popcount(m).
 __device__ __forceinline__ uint32_t select_bit(uint32_t m, uint32_t q)
@@ -601,9 +604,11 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
     const bool windowed = live;      // this half decodes a compressed page (and owes a final flush)
 
     while (wave::any(live)) {
-        // -- 1. one command per lane
+        // -- 1. one command per lane.  Two refill points per command: with >= 32 bits in the window the
+        //       command symbol (<= 15 bits) leaves >= 17 for the insert/copy extra bits, and likewise the
+        //       distance symbol for its extra bits; longer fields (rare) take the general read.
         uint32_t sym = 0, len = 0;
-        if (live) { br.ensure(15); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
+        if (live) { br.ensure(32); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
         const uint32_t sent_mask = wave::half_ballot(live && sym == kSentinel);
         const uint32_t n = sent_mask ? ctz_u32(sent_mask) : 32u;
         const bool is_cmd = live && sl < n;
@@ -611,32 +616,37 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
 
         uint32_t ins = 0, copy = 0, dist = 0, dcode = 0;
         if (is_cmd) {
-            if (sym < kSentinel) {
-                const uint32_t cell = sym >> 6;
-                const uint32_t ic = ((0x298500u >> (2u * cell)) & 3u) * 8u + ((sym >> 3) & 7u);
-                const uint32_t cc = ((0x262444u >> (2u * cell)) & 3u) * 8u + (sym & 7u);
-                const uint32_t it = W.len_code_tab[ic], ct = W.len_code_tab[24u + cc];
-                ins = (it & 0xFFFFu) + br.read(it >> 16);
-                copy = (ct & 0xFFFFu) + br.read(ct >> 16);
-                if (sym >= 128u) {                                      // explicit distance symbol
-                    uint32_t dl;
-                    br.ensure(15);
-                    dcode = decode_symbol<kLutBitsDist>(t_dist, br, dl);
-                    br.consume(dl);
-                    if (dcode >= 16u) {                                 // PageDecoder.cpp:365-390
-                        if (dcode < 16u + ndirect) dist = dcode - 15u;
-                        else {
-                            const uint32_t x = dcode - ndirect - 16u;
-                            const uint32_t nbits = min_u32(1u + (x >> (npostfix + 1u)), 24u);
-                            const uint32_t extra = br.read(nbits);
-                            const uint32_t hcode = x >> npostfix, lcode = x & ((1u << npostfix) - 1u);
-                            dist = ((((2u + (hcode & 1u)) << nbits) - 4u + extra) << npostfix) + lcode + ndirect + 1u;
-                        }
+            // insert and copy length codes (for insert-only symbols 705..727 the copy length stays 0)
+            const bool has_copy = sym < kSentinel;
+            const uint32_t cell = sym >> 6;
+            const uint32_t ic = has_copy ? ((0x298500u >> (2u * cell)) & 3u) * 8u + ((sym >> 3) & 7u) : min_u32(sym - kSentinel, 23u);
+            const uint32_t cc = ((0x262444u >> (2u * cell)) & 3u) * 8u + (sym & 7u);
+            const uint32_t it = W.len_code_tab[ic], ct = has_copy ? W.len_code_tab[24u + cc] : 0u;
+            const uint32_t ie = it >> 16, ce = ct >> 16;
+            uint32_t xi, xc;
+            if (ie + ce <= 17u) {                                       // both fields are already in the window
+                const uint32_t x = br.peek(ie + ce);
+                br.consume(ie + ce);
+                xi = x & ((1u << ie) - 1u); xc = x >> ie;
+            } else { xi = br.read(ie); xc = br.read(ce); }
+            ins = (it & 0xFFFFu) + xi;
+            copy = has_copy ? (ct & 0xFFFFu) + xc : 0u;
+            if (has_copy && sym >= 128u) {                              // explicit distance symbol
+                uint32_t dl;
+                br.ensure(32);
+                dcode = decode_symbol<kLutBitsDist>(t_dist, br, dl);
+                br.consume(dl);
+                if (dcode >= 16u) {                                     // PageDecoder.cpp:365-390
+                    if (dcode < 16u + ndirect) dist = dcode - 15u;
+                    else {
+                        const uint32_t x = dcode - ndirect - 16u;
+                        const uint32_t nbits = min_u32(1u + (x >> (npostfix + 1u)), 24u);
+                        uint32_t extra;
+                        if (nbits <= 17u) { extra = br.peek(nbits); br.consume(nbits); } else extra = br.read(nbits);
+                        const uint32_t hcode = x >> npostfix, lcode = x & ((1u << npostfix) - 1u);
+                        dist = ((((2u + (hcode & 1u)) << nbits) - 4u + extra) << npostfix) + lcode + ndirect + 1u;
                     }
                 }
-            } else {                                                    // insert-only, PageDecoder.cpp:308-317
-                const uint32_t it = W.len_code_tab[min_u32(sym - kSentinel, 23u)];
-                ins = (it & 0xFFFFu) + br.read(it >> 16);
             }
         }
 
@@ -646,24 +656,33 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
         //       command order; explicit distances and code 0 need no serial step
         const bool is_copy = is_cmd && copy > 0u;
         const uint32_t push_mask = wave::half_ballot(is_copy && dcode != 0u);
+        // A code 1..15 refers to the r-th most recent push before the command (r from the code): either
+        // a command of this round (lane `src`) or the ring carried in from earlier rounds.  All lanes
+        // whose source is already known resolve together; a chain of ring codes takes one pass per link
+        // (the lowest unresolved lane is always resolvable).
         uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
-        while (wave::any(pend != 0u)) {
-            const uint32_t k = pend ? ctz_u32(pend) : 0u;
-            const uint32_t kd = wave::half_bcast(dcode, k);
-            const uint32_t r = kd < 4u ? kd : (kd < 10u ? 0u : 1u);
-            uint32_t below = push_mask & ((1u << k) - 1u);
+        {
+            const uint32_t r = dcode < 4u ? dcode : (dcode < 10u ? 0u : 1u);
+            uint32_t below = push_mask & ((1u << sl) - 1u);
             const uint32_t cnt = (uint32_t)__popc(below);
-            for (uint32_t i = 0; i < r && below; ++i) below &= ~(1u << msb_u32(below));
-            const uint32_t from = wave::half_bcast(dist, below ? msb_u32(below) : 0u);
-            uint32_t val;
-            if (r < cnt) val = from;
-            else { const uint32_t q = r - cnt; val = q == 0u ? ring0 : q == 1u ? ring1 : q == 2u ? ring2 : ring3; }
-            if (kd >= 4u) {
-                const uint32_t j = (kd - 4u) % 6u, mag = (j >> 1) + 1u;
-                val = (j & 1u) ? val + mag : val - mag;
+            if (r >= 1u && below) below &= ~(1u << msb_u32(below));
+            if (r >= 2u && below) below &= ~(1u << msb_u32(below));
+            if (r >= 3u && below) below &= ~(1u << msb_u32(below));
+            const bool from_round = r < cnt;                            // else: carried ring entry r - cnt
+            const uint32_t src = from_round ? msb_u32(below) : 0u;
+            const uint32_t q = r - cnt;
+            const uint32_t carried = q == 0u ? ring0 : q == 1u ? ring1 : q == 2u ? ring2 : ring3;
+            const uint32_t j = dcode >= 4u ? (dcode - 4u) % 6u : 0u, mag = dcode >= 4u ? (j >> 1) + 1u : 0u;
+            while (wave::any(pend != 0u)) {
+                const bool mine = ((pend >> sl) & 1u) != 0u;
+                const bool ready = mine && (!from_round || ((pend >> src) & 1u) == 0u);
+                const uint32_t from = wave::half_shfl(dist, src);
+                if (ready) {
+                    const uint32_t val = from_round ? from : carried;
+                    dist = (j & 1u) ? val + mag : val - mag;
+                }
+                pend &= ~wave::half_ballot(ready);
             }
-            if (pend && sl == k) dist = val;
-            pend &= pend - 1u;
         }
         {
             const uint32_t below = push_mask & ((1u << sl) - 1u);
