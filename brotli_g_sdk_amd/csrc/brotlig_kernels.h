@@ -868,15 +868,24 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
                     const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
                     L.win[span0 - g0 + f + L.lit_shift[run & 31u]] = L.carry[(carry_head + f) & 63u];
                 }
-                const uint32_t J1 = F1 > prev_tail ? F1 - prev_tail : 0u;
+                // the last group also decodes the literals beyond what the round consumes (fewer than 32):
+                // they wait in the carry ring for the next round
+                const bool last_group = g + 1u == ngroups;
+                const uint32_t J1 = last_group ? rlit : (F1 > prev_tail ? F1 - prev_tail : 0u);
+                const uint32_t keep_at = carry_head + prev_tail;        // ring index of consumption index `litcount` (mod 64)
                 for (; next_j < J1; next_j += 32u) {
                     uint32_t ll;
                     br.ensure(15);
                     const uint32_t lit = decode_symbol<kLutBitsLit>(t_lit, br, ll);
                     br.consume(ll);
-                    const uint32_t idx = prev_tail + next_j - F0;
-                    const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
-                    L.win[span0 - g0 + prev_tail + next_j + L.lit_shift[run & 31u]] = (uint8_t)lit;
+                    const uint32_t f = prev_tail + next_j;
+                    if (f < litcount) {
+                        const uint32_t idx = f - F0;
+                        const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
+                        L.win[span0 - g0 + f + L.lit_shift[run & 31u]] = (uint8_t)lit;
+                    } else {
+                        L.carry[(keep_at + (f - litcount)) & 63u] = (uint8_t)lit;
+                    }
                 }
             }
             clk.lap(kPhLiterals);
@@ -988,18 +997,10 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             clk.lap(kPhCopyLevels);
         }
 
-        // literals decoded beyond what the round consumes wait in the carry ring (< 32 of them)
+        // carry ring bookkeeping: consumed entries leave at the head; when the round consumed fewer
+        // literals than were waiting (rlit == 0 then), the rest stays where it is
         if (live) {
-            const uint32_t from_carry = min_u32(prev_tail, litcount);
-            const uint32_t new_head = carry_head + from_carry;
-            const uint32_t kept = prev_tail - from_carry;               // stays in the ring (only when rlit == 0)
-            for (; next_j < rlit; next_j += 32u) {
-                uint32_t ll;
-                br.ensure(15);
-                const uint32_t lit = decode_symbol<kLutBitsLit>(t_lit, br, ll);
-                br.consume(ll);
-                L.carry[(new_head + kept + (prev_tail + next_j - litcount)) & 63u] = (uint8_t)lit;
-            }
+            const uint32_t new_head = carry_head + min_u32(prev_tail, litcount);
             carry_head = new_head;
             prev_tail = rlit + prev_tail - litcount;
         }
