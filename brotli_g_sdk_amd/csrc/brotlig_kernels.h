@@ -222,13 +222,21 @@ __device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinter
 
 // Unaligned 8-byte access (gfx950 global memory takes any byte address; hipcc emits dwordx2).
 __device__ __forceinline__ uint64_t load_u64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-// Store the low n (1..8) bytes of v at p.
+// Store the low n (1..8) bytes of v at p: at most two stores, the second overlapping the first.
 __device__ __forceinline__ void store_bytes(uint8_t* p, uint64_t v, uint32_t n)
 {
     if (n >= 8u) { __builtin_memcpy(p, &v, 8); return; }
-    if (n & 4u) { const uint32_t w = (uint32_t)v; __builtin_memcpy(p, &w, 4); p += 4; v >>= 32; }
-    if (n & 2u) { const uint16_t h = (uint16_t)v; __builtin_memcpy(p, &h, 2); p += 2; v >>= 16; }
-    if (n & 1u) *p = (uint8_t)v;
+    if (n >= 4u) {
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> (8u * (n - 4u)));
+        __builtin_memcpy(p, &lo, 4);
+        __builtin_memcpy(p + (n - 4u), &hi, 4);
+    } else if (n >= 2u) {
+        const uint16_t lo = (uint16_t)v, hi = (uint16_t)(v >> (8u * (n - 2u)));
+        __builtin_memcpy(p, &lo, 2);
+        __builtin_memcpy(p + (n - 2u), &hi, 2);
+    } else {
+        *p = (uint8_t)v;
+    }
 }
 // Where a page's bytes are while it is being decoded: positions >= win_base are in the LDS window
 // (win[pos - win_base]); everything below `flushed` (tracked by the caller) is in global memory.
