@@ -541,6 +541,12 @@ struct PageJob {
     bool     valid;
 };
 
+// dword of the compressed page at byte offset `rel`, zero beyond the readable input
+__device__ __forceinline__ uint32_t br_load(const PageJob& job, uint32_t rel)
+{
+    return rel + 4u <= job.in_limit ? load_u32(job.in + rel) : 0u;
+}
+
 template <bool kProf>
 __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t* status, unsigned long long* prof)
 {
@@ -569,7 +575,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
     {
         uint32_t my_len = 0, hdr_bytes = 0;
         if (live) {
-            const uint32_t w0 = load_u32(job.in), w1 = load_u32(job.in + 4);
+            const uint32_t w0 = br_load(job, 0u), w1 = br_load(job, 4u);
             const uint64_t h = (uint64_t)w0 | ((uint64_t)w1 << 32);
             npostfix = (uint32_t)h & 3u;
             ndirect = (((uint32_t)h >> 2) & 15u) << npostfix;
@@ -581,7 +587,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             const uint32_t table_at = 8u + base_bits + dsize_bits;
             const uint32_t bit = table_at + sl * delta_bits;
             const uint32_t wi = (bit >> 5) * 4u;
-            const uint64_t d = (uint64_t)load_u32(job.in + wi) | ((uint64_t)load_u32(job.in + wi + 4u) << 32);
+            const uint64_t d = (uint64_t)br_load(job, wi) | ((uint64_t)br_load(job, wi + 4u) << 32);
             const uint32_t delta = (uint32_t)(d >> (bit & 31u)) & ((1u << delta_bits) - 1u);
             my_len = base_size + delta;
             hdr_bytes = ((table_at + 32u * delta_bits + 31u) / 32u) * 4u;
@@ -1013,7 +1019,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             prev_tail = rlit + prev_tail - litcount;
         }
 
-        out_pos += round_bytes;
+        if (live) out_pos += round_bytes;                               // (a rejected round produced nothing)
         if (sent_mask) live = false;
     }
 
@@ -1154,7 +1160,10 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
         if (s < a.num_streams) {
             const uint8_t* p = a.in + a.streams[s].in_offset;
             StreamInfo si;
-            if (parse_stream_header(load_u32(p), load_u32(p + 4), si)) pages = si.num_pages;
+            const uint64_t in_off = a.streams[s].in_offset;
+            const bool hdr_in = in_off + 16u <= a.in_bytes;
+            if (hdr_in && parse_stream_header(load_u32(p), load_u32(p + 4), si) &&
+                in_off + si.header_bytes + 4ull * si.num_pages <= a.in_bytes) pages = si.num_pages;
             else atomicOr(a.status, kStatusBadHeader);
             DcTable& t = a.dc[s];
             t.precon = 0;

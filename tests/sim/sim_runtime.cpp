@@ -1,6 +1,10 @@
 // TEST INFRASTRUCTURE: fiber scheduler behind sim_runtime.h (x86-64 SysV only).
 #include "sim_runtime.h"
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 namespace sim {
 
 WaveState g_wave;
@@ -39,9 +43,24 @@ static void fiber_entry()
 
 constexpr size_t kStackBytes = 512 * 1024;
 
+// crash diagnostics: which lane, after which cross-lane call site, and a raw backtrace
+static void on_segv(int)
+{
+    char msg[128];
+    int n = snprintf(msg, sizeof msg, "SIM: SIGSEGV in lane %d (block %u), last cross-lane site line %d\n",
+                     g_wave.cur, g_wave.block, g_wave.site[g_wave.cur]);
+    (void)!write(2, msg, (size_t)n);
+    void* bt[32];
+    backtrace_symbols_fd(bt, backtrace(bt, 32), 2);
+    _exit(139);
+}
+
 void run_grid(uint32_t grid, void (*body)(void*), void* arg)
 {
     WaveState& w = g_wave;
+    static bool hooked = false;
+    if (!hooked) { hooked = true; static char alt[65536]; stack_t ss{alt, 0, sizeof alt}; sigaltstack(&ss, nullptr);
+        struct sigaction sa{}; sa.sa_handler = on_segv; sa.sa_flags = SA_ONSTACK; sigaction(SIGSEGV, &sa, nullptr); }
     w.grid = grid; w.body = body; w.arg = arg;
     static void* stacks[kLanes] = {nullptr};
     for (int l = 0; l < kLanes; ++l) if (!stacks[l]) stacks[l] = aligned_alloc(64, kStackBytes);

@@ -56,3 +56,20 @@ def test_sim_fuzz(sim, seed):
     outs, status = run_batch(sim, [stream], [len(data)])
     assert status == 0
     assert np.array_equal(outs[0], ref)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_sim_corrupt_streams_terminate(sim, seed):
+    """The reference has no validation (undefined behaviour on corrupt pages); this
+    decoder must at least terminate and stay inside its buffers.  Bit-flipped streams go through the
+    kernel source on the simulator: any outcome is acceptable except a crash, a hang or a write past
+    the output (checked by run_batch's guard bytes)."""
+    from brotli_g_sdk_amd import datagen as D
+    rng = np.random.default_rng(5000 + seed)
+    data = [D.text, D.records, D.samples16, D.runs][seed % 4](65536 + 9000, seed)
+    stream = E.encode(data).copy()
+    for _ in range(int(rng.integers(1, 6))):
+        pos = int(rng.integers(2, len(stream)))
+        stream[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    outs, status = run_batch(sim, [stream], [len(data)])
+    assert len(outs[0]) == len(data)
