@@ -1161,7 +1161,7 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
             const uint8_t* p = a.in + a.streams[s].in_offset;
             StreamInfo si;
             const uint64_t in_off = a.streams[s].in_offset;
-            const bool hdr_in = in_off + 16u <= a.in_bytes;
+            const bool hdr_in = in_off + 8u <= a.in_bytes;
             if (hdr_in && parse_stream_header(load_u32(p), load_u32(p + 4), si) &&
                 in_off + si.header_bytes + 4ull * si.num_pages <= a.in_bytes) pages = si.num_pages;
             else atomicOr(a.status, kStatusBadHeader);
