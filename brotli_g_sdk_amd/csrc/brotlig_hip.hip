@@ -71,7 +71,11 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     if (k0) HIP_OK(hipEventRecord(k0, s));
     hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
     if (k1) HIP_OK(hipEventRecord(k1, s));
-    hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(g_decond_grid), dim3(256), 0, s, a);
+    {   // streams over y, each stream's tiles over x; about 8 workgroups of 256 per CU in total
+        const unsigned gy = a.num_streams < 32u ? a.num_streams : 32u;
+        const unsigned gx = ((unsigned)g_decond_grid + gy - 1u) / gy;
+        hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(gx, gy), dim3(256), 0, s, a);
+    }
     HIP_OK(hipGetLastError());
     return BROTLIG_OK;
 }

@@ -45,7 +45,7 @@ struct DcTable {
     uint32_t sub_size[kMaxSubBlocks], sub_off[kMaxSubBlocks], sub_stream_off[kMaxSubBlocks + 1];
     uint32_t w[kMaxMips], h[kMaxMips], pitch[kMaxMips];
     uint32_t mip_off_bytes[kMaxMips + 1], mip_off_blocks[kMaxMips + 1];
-    uint32_t item_prefix[kMaxMips + 1];     // de-conditioning work items (row chunks) before each mip
+    uint32_t item_prefix[kMaxMips + 1];     // de-conditioning work items (2 x 32 tiles of row chunks, 64 each) before each mip
     uint32_t pad[34];
 };
 static_assert(sizeof(DcTable) == 1024, "DcTable is addressed as 1 KiB records");
@@ -547,6 +547,21 @@ __device__ __forceinline__ uint32_t br_load(const PageJob& job, uint32_t rel)
     return rel + 4u <= job.in_limit ? load_u32(job.in + rel) : 0u;
 }
 
+// byte k of the result = b0 + ... + bk (mod 256) of the dword's bytes
+__device__ __forceinline__ uint32_t byte_prefix(uint32_t x)
+{
+    const uint32_t lo = (x & 0x00FF00FFu) * 0x00010001u;              // 16-bit fields (b0, b0+b2)
+    const uint32_t hi = ((x >> 8) & 0x00FF00FFu) * 0x00010001u;       //               (b1, b1+b3)
+    const uint32_t even = lo + (hi << 16), odd = lo + hi;             // (b0, b0+b1+b2), (b0+b1, b0+..+b3)
+    return (even & 0x00FF00FFu) | ((odd & 0x00FF00FFu) << 8);
+}
+// adds the byte `c` to each byte of `x` (mod 256, no carries between bytes)
+__device__ __forceinline__ uint32_t byte_add(uint32_t x, uint32_t c)
+{
+    const uint32_t cc = (c & 0xFFu) * 0x01010101u;
+    return ((x & 0x7F7F7F7Fu) + (cc & 0x7F7F7F7Fu)) ^ ((x ^ cc) & 0x80808080u);
+}
+
 template <bool kProf>
 __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t* status, unsigned long long* prof)
 {
@@ -1030,8 +1045,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
     if (job.valid && !stored && out_pos != job.out_size) bad = true;      // a valid page fills its output exactly
 
     // ---- per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): a running byte
-    //      sum over each colour range inside the page.  Lanes take contiguous chunks; a half-wave
-    //      scan of the chunk sums supplies each chunk's starting value.
+    //      sum over each colour range inside the page.
     const bool do_delta = is_delta && !bad;
     if (wave::any(do_delta)) {
         wave::global_fence();
@@ -1042,13 +1056,35 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
                 const uint32_t ps = job.page_off, pe = job.page_off + job.out_size;
                 if (cs < pe && ps < ce) { lo = (cs > ps ? cs : ps) - ps; hi = (ce < pe ? ce : pe) - ps; }
             }
-            const uint32_t chunk = (hi - lo + 31u) / 32u;
-            const uint32_t a0 = min_u32(hi, lo + sl * chunk), a1 = min_u32(hi, a0 + chunk);
-            uint32_t sum = 0;
-            for (uint32_t i = a0; i < a1; ++i) sum += job.out[i];
-            const uint32_t incl = wave::half_scan_incl(sum & 0xFFu);
-            uint32_t run = (incl - (sum & 0xFFu)) & 0xFFu;
-            for (uint32_t i = a0; i < a1; ++i) { run = (run + job.out[i]) & 0xFFu; job.out[i] = (uint8_t)run; }
+            // 16 bytes per lane and step, 512 contiguous bytes per half-wave: byte prefix inside the
+            // lane's chunk, half-wave scan of the chunk totals, running carry from step to step.
+            uint32_t carry = 0;
+            for (uint32_t base = lo & ~15u; wave::any(base < hi); base += 512u) {
+                const uint32_t pos = base + sl * 16u;
+                const bool full = pos >= lo && pos + 16u <= hi;
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                if (full) {
+                    __builtin_memcpy(w, __builtin_assume_aligned(job.out + pos, 16), 16);
+                } else {
+                    for (uint32_t i = 0; i < 16u; ++i)
+                        if (pos + i >= lo && pos + i < hi) w[i >> 2] |= (uint32_t)job.out[pos + i] << (8u * (i & 3u));
+                }
+                w[0] = byte_prefix(w[0]);
+                w[1] = byte_add(byte_prefix(w[1]), w[0] >> 24);
+                w[2] = byte_add(byte_prefix(w[2]), w[1] >> 24);
+                w[3] = byte_add(byte_prefix(w[3]), w[2] >> 24);
+                const uint32_t total = w[3] >> 24;
+                const uint32_t incl = wave::half_scan_incl(total) & 0xFFu;
+                const uint32_t add = (carry + incl - total) & 0xFFu;
+                for (uint32_t k = 0; k < 4u; ++k) w[k] = byte_add(w[k], add);
+                if (full) {
+                    __builtin_memcpy(__builtin_assume_aligned(job.out + pos, 16), w, 16);
+                } else {
+                    for (uint32_t i = 0; i < 16u; ++i)
+                        if (pos + i >= lo && pos + i < hi) job.out[pos + i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
+                }
+                carry = (carry + wave::half_shfl(incl, 31u)) & 0xFFu;
+            }
         }
     }
     if (wave::any(bad) && bad && sl == 0u) atomicOr(status, kStatusBadPage);
@@ -1094,7 +1130,7 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
         total += nblk;
         t.mip_off_bytes[m + 1] = t.mip_off_bytes[m] + t.pitch[m] * t.h[m];
         t.mip_off_blocks[m + 1] = t.mip_off_blocks[m] + nblk;
-        t.item_prefix[m + 1] = t.item_prefix[m] + t.h[m] * ((t.pitch[m] + bb - 1u) / bb);
+        t.item_prefix[m + 1] = t.item_prefix[m] + ((t.h[m] + 1u) / 2u) * (((t.pitch[m] + bb - 1u) / bb + 31u) / 32u) * 64u;
     }
     for (uint32_t m = t.num_mips; m < kMaxMips; ++m) { t.w[m] = t.h[m] = t.pitch[m] = 0; }
     t.total_blocks = total; t.tex_bytes = total * bb;
@@ -1107,14 +1143,32 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
 // Kernel 3 (preconditioned streams only): conditioned space -> texture space, as a gather.
 // The reference scatters byte by byte (PageDecoder.cpp:243-265,:406-444); here one thread owns
 // one block-sized chunk of one texture row, reads that block's sub-blocks from the conditioned
-// staging buffer and writes the chunk (or zeros for row-pitch padding, which the reference
-// leaves at the 0 of its initial memset, src/BrotligDecoder.cpp:448).
+// staging buffer (one typed load per sub-block) and writes the chunk with one store (or zeros for
+// row-pitch padding, which the reference leaves at the 0 of its initial memset,
+// src/BrotligDecoder.cpp:448).  Work items are tiles of 2 rows x 32 chunks, one tile per
+// wavefront: under the 2x2 swizzle the 64 blocks of a tile are consecutive in every conditioned
+// sub-stream, so the reads of a wavefront are contiguous and its writes are two 512-byte rows.
+// Streams are spread over blockIdx.y, a stream's tiles over blockIdx.x.
+__device__ __forceinline__ uint64_t dc_load_sub(const uint8_t* src, uint32_t sz)
+{
+    uint64_t v = 0;
+    switch (sz) {
+    case 1: v = *src; break;
+    case 2: { uint16_t t; __builtin_memcpy(&t, src, 2); v = t; break; }
+    case 4: { uint32_t t; __builtin_memcpy(&t, src, 4); v = t; break; }
+    case 6: { uint16_t t[3]; __builtin_memcpy(t, src, 6); v = (uint64_t)t[0] | ((uint64_t)t[1] << 16) | ((uint64_t)t[2] << 32); break; }
+    case 8: __builtin_memcpy(&v, src, 8); break;
+    default: for (uint32_t i = 0; i < sz; ++i) v |= (uint64_t)src[i] << (8u * i); break;
+    }
+    return v;
+}
+
 __global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
 {
     if (a.status[2] == 0u) return;                                      // no preconditioned stream in this batch
     const uint32_t nthreads = gridDim.x * blockDim.x;
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t s = 0; s < a.num_streams; ++s) {
+    for (uint32_t s = blockIdx.y; s < a.num_streams; s += gridDim.y) {
         const DcTable& t = a.dc[s];
         if (!t.precon) continue;
         const uint64_t base = a.streams[s].out_offset;
@@ -1125,25 +1179,34 @@ __global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
             uint32_t m = 0;
             while (item >= t.item_prefix[m + 1]) ++m;
             const uint32_t W = t.w[m], H = t.h[m], pitch = t.pitch[m];
-            const uint32_t per_row = (pitch + bb - 1u) / bb;
+            const uint32_t per_row = (pitch + bb - 1u) / bb, tiles_x = (per_row + 31u) / 32u;
             const uint32_t in_mip = item - t.item_prefix[m];
-            const uint32_t row = in_mip / per_row, col = in_mip % per_row;
+            const uint32_t tile = in_mip >> 6, l = in_mip & 63u;
+            const uint32_t tr = tile / tiles_x, tc = tile - tr * tiles_x;
+            const uint32_t row = 2u * tr + ((l >> 1) & 1u), col = 32u * tc + 2u * (l >> 2) + (l & 1u);
+            if (row >= H || col >= per_row) continue;
             uint8_t* dst = tex + t.mip_off_bytes[m] + row * pitch + col * bb;
             const uint32_t nbytes = min_u32(bb, pitch - col * bb);
-            if (col >= W) { for (uint32_t i = 0; i < nbytes; ++i) dst[i] = 0; continue; }
-            // inverse of the 2x2 de-swizzle (PageDecoder.cpp:416-436): texture (row, col) -> block index
-            uint32_t block = row * W + col;
-            const uint32_t effW = W - (W & 1u), effH = H - (H & 1u);
-            if (t.swizzle && W >= 2u && H >= 2u && row < effH && col < effW) {
-                const uint32_t eff = ((row >> 1) * (effW >> 1) + (col >> 1)) * 4u + (row & 1u) * 2u + (col & 1u);
-                block = (eff / effW) * W + eff % effW;
+            uint64_t lo = 0, hi = 0;
+            if (col < W) {
+                // inverse of the 2x2 de-swizzle (PageDecoder.cpp:416-436): texture (row, col) -> block index
+                uint32_t block = row * W + col;
+                const uint32_t effW = W - (W & 1u), effH = H - (H & 1u);
+                if (t.swizzle && W >= 2u && H >= 2u && row < effH && col < effW) {
+                    const uint32_t eff = ((row >> 1) * (effW >> 1) + (col >> 1)) * 4u + (row & 1u) * 2u + (col & 1u);
+                    block = (eff / effW) * W + eff % effW;
+                }
+                for (uint32_t sub = 0; sub < t.num_sub; ++sub) {
+                    const uint32_t sz = t.sub_size[sub], off = t.sub_off[sub];
+                    const uint64_t v = dc_load_sub(cond + t.sub_stream_off[sub] + (t.mip_off_blocks[m] + block) * sz, sz);
+                    if (off < 8u) { lo |= v << (8u * off); if (off + sz > 8u) hi |= v >> (8u * (8u - off)); }
+                    else hi |= v << (8u * (off - 8u));
+                }
             }
-            for (uint32_t sub = 0; sub < t.num_sub; ++sub) {
-                const uint32_t sz = t.sub_size[sub];
-                const uint8_t* src = cond + t.sub_stream_off[sub] + (t.mip_off_blocks[m] + block) * sz;
-                uint8_t* d = dst + t.sub_off[sub];
-                for (uint32_t i = 0; i < sz; ++i) d[i] = src[i];
-            }
+            const bool aligned = ((uint64_t)(uintptr_t)dst & (uint64_t)(bb - 1u)) == 0u;
+            if (nbytes == 16u && aligned) { uint64_t v[2] = {lo, hi}; __builtin_memcpy(__builtin_assume_aligned(dst, 16), v, 16); }
+            else if (nbytes == 8u && bb == 8u && aligned) __builtin_memcpy(__builtin_assume_aligned(dst, 8), &lo, 8);
+            else for (uint32_t i = 0; i < nbytes; ++i) dst[i] = (uint8_t)((i < 8u ? lo >> (8u * i) : hi >> (8u * (i - 8u))));
         }
     }
 }

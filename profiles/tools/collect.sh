@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the per-round profile set on an MI355X box (run through gpurun from the repo root):
+#   bash profiles/tools/collect.sh <tag>
+# Writes raw rocprofv3 output under gpurun_out/<tag>/; profiles/tools/summarize.py turns it into the
+# committed summaries.  PMC passes are separate runs with --kernel-trace only (no sys/hip traces).
+set -u
+tag=${1:-final}
+root=$(pwd)
+out=$root/gpurun_out/$tag
+mkdir -p "$out"
+export TMPDIR=/tmp
+python bench.py > "$out/bench.json" 2> "$out/bench.err"
+python bench.py --workload bc3 --streams 256 --no-cpu-baseline > "$out/bench_bc3.json" 2>> "$out/bench.err"
+python bench.py --workload runs --streams 1 --no-cpu-baseline > "$out/bench_runs.json" 2>> "$out/bench.err"
+python bench.py --workload text --no-cpu-baseline > "$out/bench_text.json" 2>> "$out/bench.err"
+for k in mixed text runs bc3; do python profiles/phase_profile.py $k; done > "$out/phase_profile.jsonl" 2>> "$out/bench.err"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o f -- python "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$out/trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o f -- python "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o f -- python "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1
+# keep only what the summariser needs (the merge-back limit is 64 MiB)
+find "$out" -name '*_kernel_trace.csv' -size +8M -delete
+find "$out" -name '*agent_info*' -delete
+ls -laR "$out" | tail -40

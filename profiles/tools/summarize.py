@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<tag>/ (written by collect.sh on the MI355X box) into the committed summaries
+profiles/r<NN>_<tag>_*.  Usage: python profiles/tools/summarize.py <tag> <round> "<kernel label>"."""
+import csv, glob, json, os, shutil, sys
+
+tag, rnd, label = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+pre = os.path.join(dst, f"r{rnd}_{tag}_")
+
+for name in ("bench", "bench_bc3", "bench_runs", "bench_text"):
+    p = os.path.join(src, name + ".json")
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, pre + name + ".json")
+shutil.copy(os.path.join(src, "phase_profile.jsonl"), pre + "phase_profile.jsonl")
+bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(stats)))
+with open(pre + "kernel_trace_stats.md", "w") as f:
+    f.write(f"# Round {int(rnd)}, {label} -- rocprofv3 --kernel-trace --stats\n\n")
+    f.write("Command (MI355X box, from /tmp with TMPDIR=/tmp): `rocprofv3 --kernel-trace --stats --output-format csv "
+            "-d gpurun_out/%s/trace -o f -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline`\n" % tag)
+    f.write("(default workload: %s).  Source: `f_kernel_stats.csv`.\n\n" % bench["config"]["workload"])
+    f.write("| kernel | calls | total ns | average ns | % | min ns | max ns |\n|---|---|---|---|---|---|---|\n")
+    dec_avg = None
+    for r in rows[:10]:
+        f.write("| `%s` | %s | %s | %d | %s | %s | %s |\n" % (r["Name"][:80], r["Calls"], r["TotalDurationNs"],
+                float(r["AverageNs"]), r["Percentage"], r["MinNs"], r["MaxNs"]))
+        if "brotlig_decode_kernel" in r["Name"] and dec_avg is None:
+            dec_avg = float(r["AverageNs"]) / 1e6
+    f.write("\n`brotlig_decode_kernel` average under rocprofv3: %.3f ms (2 warm-up + 5 timed + 1 verification launch).  "
+            "bench.py's own HIP-event average over the 5 timed launches of the un-profiled run of the same "
+            "build: %.3f ms (`%s`).\n" % (dec_avg, bench["roofline"]["kernel_ms"], os.path.basename(pre + "bench.json")))
+
+def pmc(sub, counter):
+    p = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(p))
+            if r["Counter_Name"] == counter and "brotlig_decode_kernel" in r["Kernel_Name"]]
+    return sum(vals) / len(vals), len(vals)
+
+fetch, nf = pmc("pmc_fetch", "FETCH_SIZE")
+write, nw = pmc("pmc_write", "WRITE_SIZE")
+alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+j = {
+    "kernel": "brotlig_decode_kernel", "build": label, "workload": bench["config"]["workload"],
+    "launches_averaged": {"FETCH_SIZE": nf, "WRITE_SIZE": nw},
+    "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
+    "fetch_bytes_per_launch": fetch * 1024, "write_bytes_per_launch": write * 1024,
+    "traffic_bytes_per_launch_raw": (fetch + write) * 1024,
+    "traffic_bytes_per_launch_fetch_doubled": (2 * fetch + write) * 1024,
+    "algorithmic_bytes_per_launch": alg,
+    "note": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only. "
+            "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half of a wide coalesced streaming read; "
+            "narrow/scattered reads (this kernel: 8-byte loads) and WRITE_SIZE are uncalibrated, so both the raw "
+            "and the read-doubled sums are given.",
+}
+json.dump(j, open(pre + "hbm_traffic.json", "w"), indent=1)
+print(json.dumps({"decode_ms_rocprof": dec_avg, "decode_ms_bench": bench["roofline"]["kernel_ms"],
+                  "fetch_GB": fetch * 1024 / 1e9, "write_GB": write * 1024 / 1e9, "alg_GB": alg / 1e9}))
