@@ -94,8 +94,8 @@ constexpr uint32_t kShortCopy = 32;         // copies up to this length run one-
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
 // flushed to global memory in aligned 16-byte stores when it slides.
-constexpr uint32_t kWin = 1280;
-constexpr uint32_t kHist = 640;             // history kept across a slide (>= kWin / 2: see the slide below)
+constexpr uint32_t kWin = 1024;
+constexpr uint32_t kHist = 512;             // history kept across a slide (>= kWin / 2: see the slide below)
 constexpr uint32_t kRoundMax = kWin - kHist;
 constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
 
@@ -129,7 +129,7 @@ struct __attribute__((aligned(16))) PageLds {
     uint64_t stage[kStageBytes / 8];        // per group: source bytes of far copies (older than the window)
     uint32_t sorted_icp[(kIcpAlphabet + 2) / 3];       // symbols in canonical-code order, three 10-bit fields per word
     uint32_t sorted_dist[(kDistAlphabet + 2) / 3];
-    uint32_t sorted_lit[(kLitAlphabet + 2) / 3];
+    uint32_t sorted_lit[kLitAlphabet / 4];             // literals fit a byte each: plain byte array
     uint16_t limit[3][16] __attribute__((aligned(16)));     // per code length: exclusive upper bound, left-justified to 15 bits
     uint32_t first_offs[3][16]; // per code length: first code (left-justified) | index of its first symbol in sorted_* << 16
     uint32_t start_bits[kRoundMax / 32];    // per group: bit p set <=> a command's piece starts at group byte p
@@ -170,30 +170,39 @@ struct BitReader {
     uint32_t next;          // byte offset of the next 8-byte load, dword aligned relative to base
     uint64_t queue;
     uint32_t queued;        // 0, 32 or 64
-    uint64_t flight;
+    uint64_t flight;        // raw 8 bytes as loaded; `flight_sh` says how to turn them into the wanted ones
+    uint32_t flight_sh;
 
-    __device__ __forceinline__ uint64_t load8(uint32_t rel) const
+    // Issues the 8-byte load for byte offset `rel` without touching its result: near the end of the
+    // readable input the load is moved back to the last 8 readable bytes (always inside the input
+    // buffer: at least 12 bytes of headers precede every page) and `sh` is the right shift that
+    // aligns it (>= 64: nothing readable at `rel`).  Branch-free on purpose: a conditional load
+    // would reach `flight` through a register copy, and the copy would wait for the load just issued.
+    __device__ __forceinline__ uint64_t load8_raw(uint32_t rel, uint32_t& sh) const
     {
-        if (rel + 8u <= limit) return load_u64u_g(base + rel);
-        uint64_t v = 0;
-        if (rel < limit) v = *reinterpret_cast<const uint32_t*>(base + rel);       // limit is a multiple of 4
-        return v;
+        const bool inside = rel + 8u <= limit;
+        const int32_t a = inside ? (int32_t)rel : (int32_t)limit - 8;
+        sh = inside ? 0u : (rel - (uint32_t)a) * 8u;
+        return load_u64u_g(base + a);
     }
+    static __device__ __forceinline__ uint64_t settle(uint64_t raw, uint32_t sh) { return sh >= 64u ? 0ull : raw >> sh; }
     __device__ __forceinline__ void init(const uint8_t* b, uint32_t lim, uint32_t start)
     {
         base = b; limit = lim;
         const uint32_t a = start & ~3u, skip = (start & 3u) * 8u;
-        const uint64_t first = load8(a);
+        uint32_t sh0;
+        const uint64_t raw0 = load8_raw(a, sh0);
+        next = a + 8u;
+        flight = load8_raw(next, flight_sh); next += 8u;
+        const uint64_t first = settle(raw0, sh0);
         buf = (uint64_t)((uint32_t)first >> skip);
         avail = 32u - skip;
         queue = first >> 32; queued = 32u;
-        next = a + 8u;
-        flight = load8(next); next += 8u;
         if (avail < 32u) refill();
     }
     __device__ __forceinline__ void refill()
     {
-        if (queued == 0u) { queue = flight; queued = 64u; flight = load8(next); next += 8u; }
+        if (queued == 0u) { queue = settle(flight, flight_sh); queued = 64u; flight = load8_raw(next, flight_sh); next += 8u; }
         buf |= (uint64_t)(uint32_t)queue << avail;
         queue >>= 32; queued -= 32u;
         avail += 32u;
@@ -345,6 +354,16 @@ __device__ __forceinline__ void sorted_put(uint32_t* words, uint32_t i, uint32_t
     const uint32_t w = (i * 43691u) >> 17;
     atomicOr(&words[w], sym << (10u * (i - 3u * w)));
 }
+// the literal table (256 symbols) keeps its symbols as bytes instead
+__device__ __forceinline__ uint32_t table_sym(const TableRef& t, uint32_t i)
+{
+    return t.alphabet == kLitAlphabet ? (uint32_t)reinterpret_cast<const uint8_t*>(t.sorted)[i] : sorted_get(t.sorted, i);
+}
+__device__ __forceinline__ void table_set_sym(const TableRef& t, uint32_t i, uint32_t sym)   // packed words pre-zeroed
+{
+    if (t.alphabet == kLitAlphabet) reinterpret_cast<uint8_t*>(t.sorted)[i] = (uint8_t)sym;
+    else sorted_put(t.sorted, i, sym);
+}
 
 // Decode one symbol from `br` (needs avail >= 15 on entry).  Returns symbol, sets len.
 // kBits = index width of the table's primary LUT.  Codes longer than that take the canonical route:
@@ -372,7 +391,7 @@ __device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitRe
     uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
     idx = min_u32(idx, t.alphabet - 1u);
     len = l;
-    return sorted_get(t.sorted, idx);
+    return table_sym(t, idx);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -466,7 +485,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         const uint32_t blk = (A + 31u) / 32u;
         const uint32_t b0 = sl * blk, b1 = min_u32(A, b0 + blk);
         if (is_complex) for (uint32_t l = 0; l < 16u; ++l) cnt[l * 32u + sl] = 0;
-        if (is_complex) for (uint32_t w = sl; w < (A + 2u) / 3u; w += 32u) t.sorted[w] = 0u;
+        if (is_complex && A != kLitAlphabet) for (uint32_t w = sl; w < (A + 2u) / 3u; w += 32u) t.sorted[w] = 0u;
         wave::sync();
         if (is_complex)
             for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = L.win[s] & 15u; if (l) cnt[l * 32u + sl]++; }
@@ -488,7 +507,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         if (is_complex)
             for (uint32_t s = b0; s < b1; ++s) {
                 const uint32_t l = L.win[s] & 15u;
-                if (l) { const uint32_t p = cnt[l * 32u + sl]++; sorted_put(t.sorted, min_u32(p, A - 1u), s); }
+                if (l) { const uint32_t p = cnt[l * 32u + sl]++; table_set_sym(t, min_u32(p, A - 1u), s); }
             }
         wave::sync();
         // primary LUT, one entry per lane per step
@@ -502,7 +521,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
                     const uint32_t fo = t.first_offs[l];
                     uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
                     idx = min_u32(idx, A - 1u);
-                    entry = (sorted_get(t.sorted, idx) << 4) | l;
+                    entry = (table_sym(t, idx) << 4) | l;
                 }
                 t.lut[e] = (uint16_t)entry;
             }
@@ -586,7 +605,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
     uint32_t npostfix = 0, ndirect = 0;
     bool is_delta = false;
     BitReader br;
-    br.base = job.in; br.limit = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0;
+    br.base = job.in; br.limit = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.flight_sh = 64;
     {
         uint32_t my_len = 0, hdr_bytes = 0;
         if (live) {
@@ -843,6 +862,9 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             if (multi_group) { F0 = wave::half_sum(mine_before); F1 = F0 + wave::half_sum(nlit); }
             const uint32_t run_mask = wave::half_ballot(nlit != 0u);
             const uint32_t piece_mask = wave::half_ballot(in_group);
+            // one literal run in the group (long inserts): its shift is all a literal needs
+            const bool one_run = (run_mask & (run_mask - 1u)) == 0u;
+            const uint32_t shift1 = wave::half_bcast(rel0 - lit_a, run_mask ? ctz_u32(run_mask) : 0u);
             if (on && sl < kRoundMax / 32u) {
                 L.start_bits[sl] = 0u;
                 L.lit_bits[sl] = 0u;
@@ -909,9 +931,13 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
                     br.consume(ll);
                     const uint32_t f = prev_tail + next_j;
                     if (f < litcount) {
-                        const uint32_t idx = f - F0;
-                        const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
-                        L.win[span0 - g0 + f + L.lit_shift[run & 31u]] = (uint8_t)lit;
+                        uint32_t shift = shift1;
+                        if (!one_run) {
+                            const uint32_t idx = f - F0;
+                            const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
+                            shift = L.lit_shift[run & 31u];
+                        }
+                        L.win[span0 - g0 + f + shift] = (uint8_t)lit;
                     } else {
                         L.carry[(keep_at + (f - litcount)) & 63u] = (uint8_t)lit;
                     }
