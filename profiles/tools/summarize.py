@@ -57,5 +57,24 @@ j = {
             "and the read-doubled sums are given.",
 }
 json.dump(j, open(pre + "hbm_traffic.json", "w"), indent=1)
+# SQ counters (two passes), decode kernel only, averaged over its dispatches
+sq = {}
+for sub in ("pmc_sq1", "pmc_sq2"):
+    ps = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    if not ps: continue
+    acc = {}
+    for r in csv.DictReader(open(ps[0])):
+        if "brotlig_decode_kernel" in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, v in acc.items(): sq[k] = sum(v) / len(v)
+if sq:
+    with open(pre + "pmc_sq_counters.md", "w") as f:
+        f.write(f"# Round {int(rnd)}, {label} -- rocprofv3 --pmc SQ counters (two separate passes, kernel-trace only)\n\n")
+        f.write("Workload: bench.py default (%s).  Values per dispatch of `brotlig_decode_kernel`, summed over all "
+                "SEs/XCDs as rocprofv3 reports them.\n\n| counter | per dispatch |\n|---|---|\n" % bench["config"]["workload"])
+        for k in sorted(sq): f.write("| %s | %.4g |\n" % (k, sq[k]))
+        if "SQ_WAVE_CYCLES" in sq and "SQ_ACTIVE_INST_VALU" in sq:
+            f.write("\nVALU-active / wave cycles: %.3f; wait-any / wave cycles: %.3f; VALU instructions per decompressed GiB: %.3g\n" % (
+                sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], sq.get("SQ_WAIT_ANY", 0) / sq["SQ_WAVE_CYCLES"], sq.get("SQ_INSTS_VALU", 0) / 4.0))
 print(json.dumps({"decode_ms_rocprof": dec_avg, "decode_ms_bench": bench["roofline"]["kernel_ms"],
                   "fetch_GB": fetch * 1024 / 1e9, "write_GB": write * 1024 / 1e9, "alg_GB": alg / 1e9}))
