@@ -162,7 +162,7 @@ class BatchDecoder:
             return total.value, kern.value
 
     PHASES = ("setup", "tables", "commands", "ring", "positions", "literals", "group_setup", "level_tail",
-              "delta", "total", "rounds", "levels", "lv_short", "lv_bytes", "lv_long_and_far", "unused")
+              "delta", "total", "rounds", "levels", "lv_short", "lv_bytes", "lv_long_and_far", "solo_rounds")
 
     def phase_profile(self):
         """Per-phase shader-clock sums from the phase-timer twin of the decode kernel (diagnostics)."""

@@ -250,9 +250,8 @@ __device__ __forceinline__ void store_bytes(uint8_t* p, uint64_t v, uint32_t n)
 // Where a page's bytes are while it is being decoded: positions >= win_base are in the LDS window
 // (win[pos - win_base]); everything below `flushed` (tracked by the caller) is in global memory.
 struct OutView {
-    uint8_t* out;
-    uint8_t* win;
-    uint32_t win_base;      // page position of win[0]; multiple of 16
+    uint8_t* win;           // the LDS window
+    uint32_t win_base;      // page position of win[0]
 };
 
 // Eight bytes of an LZ77 copy's source pattern (which lies entirely in LDS at `s`), starting at offset
@@ -314,19 +313,19 @@ __device__ __forceinline__ Team make_team(uint32_t job_mask, uint32_t sl)
 // Store window bytes [from, to) of the page to global memory: up to 15 head bytes, then aligned
 // 16-byte pieces (one per lane per step), then -- only when `exact` -- the tail bytes.  Without
 // `exact` the range is cut at the last 16-byte boundary.  Returns the new flushed position.
-__device__ __forceinline__ uint32_t flush_window(const OutView& o, uint32_t from, uint32_t to, bool exact, uint32_t sl)
+__device__ __forceinline__ uint32_t flush_window(uint8_t* out, const OutView& o, uint32_t from, uint32_t to, bool exact, uint32_t sl)
 {
     const uint32_t end = exact ? to : (to & ~15u);
     if (end <= from) return from;
     const uint32_t a = min_u32(end, (from + 15u) & ~15u);
-    for (uint32_t p = from + sl; p < a; p += 32u) o.out[p] = o.win[p - o.win_base];
+    for (uint32_t p = from + sl; p < a; p += 32u) out[p] = o.win[p - o.win_base];
     const uint32_t e16 = end & ~15u;
     for (uint32_t p = a + 16u * sl; p < e16; p += 512u) {
         uint64_t v[2];
         __builtin_memcpy(v, o.win + (p - o.win_base), 16);
-        __builtin_memcpy(o.out + p, v, 16);
+        __builtin_memcpy(out + p, v, 16);
     }
-    for (uint32_t p = (e16 > a ? e16 : a) + sl; p < end; p += 32u) o.out[p] = o.win[p - o.win_base];
+    for (uint32_t p = (e16 > a ? e16 : a) + sl; p < end; p += 32u) out[p] = o.win[p - o.win_base];
     return end;
 }
 // r <- (r + step) mod d, for r < d
@@ -581,77 +580,168 @@ __device__ __forceinline__ uint32_t byte_add(uint32_t x, uint32_t c)
     return ((x & 0x7F7F7F7Fu) + (cc & 0x7F7F7F7Fu)) ^ ((x ^ cc) & 0x80808080u);
 }
 
+// The job of global page index `g` (meaningful when `ok`): stream lookup, page table walk
+// (src/BrotligDecoder.cpp:310-314), bounds against the caller's buffers.
+__device__ inline PageJob fetch_job(const DecodeArgs& a, uint32_t g, bool ok)
+{
+    PageJob job;
+    job.valid = ok;
+    job.in = a.in; job.out = a.out; job.in_size = job.out_size = 0; job.in_limit = 0; job.page_size = kMinPageSize;
+    job.page_off = 0; job.dc = nullptr;
+    if (job.valid) {
+        // stream lookup: largest s with page_base[s] <= g
+        uint32_t lo = 0, hi = a.num_streams;
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (a.page_base[mid] <= g) lo = mid; else hi = mid; }
+        const uint32_t i = g - a.page_base[lo];
+        const uint64_t s_in = a.streams[lo].in_offset, s_out = a.streams[lo].out_offset;
+        const uint8_t* sp = a.in + s_in;
+        StreamInfo si;
+        parse_stream_header(load_u32(sp), load_u32(sp + 4), si);
+        const uint8_t* table = sp + si.header_bytes;
+        const uint8_t* pages = table + 4u * si.num_pages;
+        const uint32_t off = i ? load_u32(table + 4u * i) : 0u;                      // src/BrotligDecoder.cpp:310
+        job.in_size = i + 1u < si.num_pages ? load_u32(table + 4u * (i + 1u)) - off : load_u32(table);   // :311
+        job.out_size = (i + 1u == si.num_pages && si.last_page_size) ? si.last_page_size : si.page_size;  // :314
+        job.page_size = si.page_size;
+        job.in = pages + off;
+        const uint64_t abs_in = (uint64_t)(job.in - a.in);
+        const uint64_t room = abs_in < a.in_bytes ? a.in_bytes - abs_in : 0;
+        job.in_limit = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ((room + 3ull) & ~3ull));
+        const uint64_t abs_out = s_out + (uint64_t)i * si.page_size;
+        uint8_t* dst_base = si.preconditioned ? a.scratch : a.out;
+        job.page_off = i * si.page_size;
+        job.dc = si.preconditioned ? &a.dc[lo] : nullptr;
+        job.out = dst_base + abs_out;
+        if (abs_out + job.out_size > a.out_bytes || job.in_size > room || dst_base == nullptr) {
+            job.valid = false;
+            atomicOr(a.status, kStatusBadPage);
+        }
+    }
+    return job;
+}
+
+// The persistent page loop of one wavefront.  Each 32-lane half decodes its own page and takes the
+// next page from the work counter as soon as it is done, independently of the other half: pages
+// differ a lot in their number of rounds (stored, run-length and text pages side by side), and a
+// half that waited for its neighbour would idle for the difference.  The wavefront's control flow
+// stays uniform: one iteration = (page start for the halves that need one) + (one round for the
+// halves inside a page) + (page end for the halves whose page just finished), each under per-half
+// predicates.
 template <bool kProf>
-__device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t* status, unsigned long long* prof)
+__device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
 {
     PhaseClock<kProf> clk;
     clk.start();
     const uint32_t lane = wave::lane_id();
     const uint32_t sl = lane & 31u;
     PageLds& L = W.page[lane >> 5];
+    uint32_t* const status = a.status;
+    const uint32_t total = a.page_base[a.num_streams];
+    const uint32_t resync_quarters = a.status[3];                       // pairing policy, set by the prepare kernel
 
-    const bool stored = job.valid && job.in_size == job.out_size;       // PageDecoder.cpp:70-76
-    bool live = job.valid && !stored;
-
-    // ---- stored page: plain copy, 4 bytes per lane per step
-    if (stored) {
-        const uint32_t words = job.out_size >> 2;
-        for (uint32_t i = sl; i < words; i += 32u)
-            reinterpret_cast<uint32_t*>(job.out)[i] = load_u32(job.in + 4u * i);
-        for (uint32_t i = (words << 2) + sl; i < job.out_size; i += 32u) job.out[i] = job.in[i];
-    }
-
-    // ---- page header + sub-stream size table (PageDecoder.cpp:79-121)
-    uint32_t npostfix = 0, ndirect = 0;
-    bool is_delta = false;
-    BitReader br;
-    br.base = job.in; br.limit = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.flight_sh = 64;
-    {
-        uint32_t my_len = 0, hdr_bytes = 0;
-        if (live) {
-            const uint32_t w0 = br_load(job, 0u), w1 = br_load(job, 4u);
-            const uint64_t h = (uint64_t)w0 | ((uint64_t)w1 << 32);
-            npostfix = (uint32_t)h & 3u;
-            ndirect = (((uint32_t)h >> 2) & 15u) << npostfix;
-            is_delta = (((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr;       // PageDecoder.cpp:87-88
-            const uint32_t base_bits = bit_width_u32((job.in_size + 31u) / 32u);
-            const uint32_t dsize_bits = bit_width_u32(bit_width_u32(job.in_size - 1u));
-            const uint32_t base_size = (uint32_t)(h >> 8) & ((1u << base_bits) - 1u);
-            const uint32_t delta_bits = (uint32_t)(h >> (8u + base_bits)) & ((1u << dsize_bits) - 1u);
-            const uint32_t table_at = 8u + base_bits + dsize_bits;
-            const uint32_t bit = table_at + sl * delta_bits;
-            const uint32_t wi = (bit >> 5) * 4u;
-            const uint64_t d = (uint64_t)br_load(job, wi) | ((uint64_t)br_load(job, wi + 4u) << 32);
-            const uint32_t delta = (uint32_t)(d >> (bit & 31u)) & ((1u << delta_bits) - 1u);
-            my_len = base_size + delta;
-            hdr_bytes = ((table_at + 32u * delta_bits + 31u) / 32u) * 4u;
-        }
-        const uint32_t incl = wave::half_scan_incl(my_len);
-        if (live) br.init(job.in, job.in_limit, hdr_bytes + incl - my_len);
-    }
-
-    clk.lap(kPhSetup);
-    // ---- three prefix codes: ICP, distance, literal (PageDecoder.cpp:125-147)
+    // the three prefix codes of a page: ICP, distance, literal (PageDecoder.cpp:125-147)
     const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first_offs[0], kIcpAlphabet, kLutBitsIcp};
     const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist};
     const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit};
-    build_table(t_icp, L, br, live, sl);
-    build_table(t_dist, L, br, live, sl);
-    build_table(t_lit, L, br, live, sl);
-    clk.lap(kPhTables);
 
-    // ---- rounds (PageDecoder.cpp:174-236; format A.6)
+    // ---- per-half state of the page under construction
+    PageJob job = fetch_job(a, 0u, false);
+    bool live = false;               // inside a compressed page
+    bool finished = false;           // the work counter ran out for this half
+    uint32_t npostfix = 0, ndirect = 0;
+    bool is_delta = false;
+    BitReader br;
+    br.base = a.in; br.limit = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.flight_sh = 64;
     uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16;             // PageDecoder.cpp:150-153
     uint32_t out_pos = 0;            // bytes of the page produced so far
     uint32_t prev_tail = 0;          // literals decoded but not yet consumed
     uint32_t carry_head = 0;
-    uint32_t rounds_left = job.page_size / 64u + 4u;                    // every full round emits >= 64 bytes
+    uint32_t rounds_left = 0;
     bool bad = false;
-    OutView view{job.out, L.win, 0u};
+    OutView view{L.win, 0u};
     uint32_t flushed = 0;            // page bytes below this are in global memory
-    const bool windowed = live;      // this half decodes a compressed page (and owes a final flush)
 
-    while (wave::any(live)) {
+    for (;;) {
+        // ---- page start.  A half without a page takes one -- unless the other half is within
+        //      resync_quarters / 4 of finishing its own page: then it waits and both start together (one
+        //      joint table build instead of two single ones).  The prepare kernel sets the threshold per
+        //      launch: 1 when neighbouring pages differ in cost (a free half starts over at once), 4 when
+        //      they are alike -- then the halves stay in step, which keeps rounds of the same shape
+        //      paired (measured on the BC3 config: 7 % faster in step than out of phase).
+        {
+            const uint32_t near_end = (live && (job.out_size - out_pos) * 4u < job.out_size * resync_quarters) ? 1u : 0u;
+            const uint32_t other_near = wave::other_half(near_end);
+            const bool want = !live && !finished && other_near == 0u;
+            if (wave::any(want)) {
+                clk.lap(kPhDelta);
+                // Stored pages (PageDecoder.cpp:70-76) are copied on the spot and rejected ones skipped: a
+                // half keeps taking pages until it holds a compressed one, so that both halves reach the
+                // table build together.
+                bool need = want, start = false;
+                while (wave::any(need)) {
+                    uint32_t g = 0;
+                    if (need && sl == 0u) g = atomicAdd(a.work_counter, 1u);
+                    g = wave::half_bcast(g, 0u);
+                    const bool got = need && g < total;
+                    if (need && !got) { finished = true; need = false; }
+                    {
+                        const PageJob nj = fetch_job(a, g, got);
+                        if (got) job = nj;
+                    }
+                    const bool fresh = got && job.valid;
+                    const bool stored = fresh && job.in_size == job.out_size;
+                    if (stored) {                                       // plain copy, 4 bytes per lane per step
+                        const uint32_t words = job.out_size >> 2;
+                        for (uint32_t i = sl; i < words; i += 32u)
+                            reinterpret_cast<uint32_t*>(job.out)[i] = load_u32(job.in + 4u * i);
+                        for (uint32_t i = (words << 2) + sl; i < job.out_size; i += 32u) job.out[i] = job.in[i];
+                    }
+                    if (fresh && !stored) { start = true; need = false; }
+                }
+
+                // ---- page header + sub-stream size table (PageDecoder.cpp:79-121)
+                {
+                    uint32_t my_len = 0, hdr_bytes = 0;
+                    if (start) {
+                        const uint32_t w0 = br_load(job, 0u), w1 = br_load(job, 4u);
+                        const uint64_t h = (uint64_t)w0 | ((uint64_t)w1 << 32);
+                        npostfix = (uint32_t)h & 3u;
+                        ndirect = (((uint32_t)h >> 2) & 15u) << npostfix;
+                        is_delta = (((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr;       // PageDecoder.cpp:87-88
+                        const uint32_t base_bits = bit_width_u32((job.in_size + 31u) / 32u);
+                        const uint32_t dsize_bits = bit_width_u32(bit_width_u32(job.in_size - 1u));
+                        const uint32_t base_size = (uint32_t)(h >> 8) & ((1u << base_bits) - 1u);
+                        const uint32_t delta_bits = (uint32_t)(h >> (8u + base_bits)) & ((1u << dsize_bits) - 1u);
+                        const uint32_t table_at = 8u + base_bits + dsize_bits;
+                        const uint32_t bit = table_at + sl * delta_bits;
+                        const uint32_t wi = (bit >> 5) * 4u;
+                        const uint64_t d = (uint64_t)br_load(job, wi) | ((uint64_t)br_load(job, wi + 4u) << 32);
+                        const uint32_t delta = (uint32_t)(d >> (bit & 31u)) & ((1u << delta_bits) - 1u);
+                        my_len = base_size + delta;
+                        hdr_bytes = ((table_at + 32u * delta_bits + 31u) / 32u) * 4u;
+                    }
+                    const uint32_t incl = wave::half_scan_incl(my_len);
+                    if (start) br.init(job.in, job.in_limit, hdr_bytes + incl - my_len);
+                }
+                clk.lap(kPhSetup);
+                build_table(t_icp, L, br, start, sl);
+                build_table(t_dist, L, br, start, sl);
+                build_table(t_lit, L, br, start, sl);
+                if (start) {
+                    ring0 = 4; ring1 = 11; ring2 = 15; ring3 = 16;
+                    out_pos = 0; prev_tail = 0; carry_head = 0; flushed = 0; bad = false;
+                    rounds_left = job.page_size / 64u + 4u;             // every full round emits >= 64 bytes
+                    view.win_base = 0u;
+                    live = true;
+                }
+                clk.lap(kPhTables);
+            }
+        }
+        if (!wave::any(live)) break;                                    // a half without a page has none left to take
+        const bool in_page = live;
+
+        // ---- rounds (PageDecoder.cpp:174-236; format A.6) until a page ends
+        do {
         // -- 1. one command per lane.  Two refill points per command: with >= 32 bits in the window the
         //       command symbol (<= 15 bits) leaves >= 17 for the insert/copy extra bits, and likewise the
         //       distance symbol for its extra bits; longer fields (rare) take the general read.
@@ -700,6 +790,10 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
 
         clk.lap(kPhCommands);
         clk.count(kPhRounds, 1);
+        if constexpr (kProf) {                                          // rounds in which one half has no page left
+            const uint64_t lm = wave::ballot64(live);
+            clk.count(kPhSlow, (((uint32_t)lm != 0u) != ((uint32_t)(lm >> 32) != 0u)) ? 1u : 0u);
+        }
         // -- 2. distance ring (PageDecoder.cpp:345-364, :396-403): codes 1..15 are resolved in
         //       command order; explicit distances and code 0 need no serial step
         const bool is_copy = is_cmd && copy > 0u;
@@ -799,7 +893,7 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             const bool slide = on && out_pos + g1 > view.win_base + kWin;
             wave::sync();
             if (wave::any(slide)) {
-                if (slide) flushed = flush_window(view, flushed, gpos, false, sl);
+                if (slide) flushed = flush_window(job.out, view, flushed, gpos, false, sl);
                 const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
                 const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
                 for (uint32_t i0 = 0; wave::any(i0 < count); i0 += 256u) {
@@ -1062,17 +1156,17 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
 
         if (live) out_pos += round_bytes;                               // (a rejected round produced nothing)
         if (sent_mask) live = false;
-    }
+        } while (!wave::any(in_page && !live));
 
-    wave::sync();
-    if (wave::any(windowed)) {
-        if (windowed) flushed = flush_window(view, flushed, out_pos, true, sl);
-    }
-    if (job.valid && !stored && out_pos != job.out_size) bad = true;      // a valid page fills its output exactly
+        // ---- page end for the halves whose page finished (or was rejected) in the last round
+        const bool ended = in_page && !live;
+        wave::sync();
+        if (ended) flushed = flush_window(job.out, view, flushed, out_pos, true, sl);
+        if (ended && out_pos != job.out_size) bad = true;                // a valid page fills its output exactly
 
     // ---- per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): a running byte
     //      sum over each colour range inside the page.
-    const bool do_delta = is_delta && !bad;
+    const bool do_delta = ended && is_delta && !bad;
     if (wave::any(do_delta)) {
         wave::global_fence();
         for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
@@ -1113,9 +1207,10 @@ __device__ inline void decode_page_pair(WaveLds& W, const PageJob& job, uint32_t
             }
         }
     }
-    if (wave::any(bad) && bad && sl == 0u) atomicOr(status, kStatusBadPage);
+    if (ended && bad && sl == 0u) atomicOr(status, kStatusBadPage);
+    }
     clk.lap(kPhDelta);
-    clk.flush(prof, lane);
+    clk.flush(a.prof, lane);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1272,6 +1367,39 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
         running += first_half_total + second_half_total;
     }
     if (lane == 0u) { a.page_base[a.num_streams] = running; a.work_counter[0] = 0u; }
+
+    // ---- pairing policy of the decode kernel (decode_pages): do neighbouring pages differ in cost?
+    //      Up to 2048 evenly spaced page pairs (2k, 2k+1) are compared by compressed size; when more
+    //      than a quarter of them differ by over 25 % (a mix of page kinds side by side) the two halves
+    //      of a wavefront run free of each other, otherwise they stay in step (status word 3: the number
+    //      of quarters of a page within which a free half waits for its neighbour -- 1 or 4).
+    wave::global_fence();
+    const uint32_t pairs = running / 2u, nsamp = min_u32(pairs, 2048u);
+    uint32_t differ = 0, valid = 0;
+    for (uint32_t j = lane; j < nsamp; j += 64u) {
+        const uint32_t g = 2u * (uint32_t)(((uint64_t)j * pairs) / nsamp);
+        uint32_t lo = 0, hi = a.num_streams;
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (a.page_base[mid] <= g) lo = mid; else hi = mid; }
+        const uint32_t i = g - a.page_base[lo];
+        const uint32_t np = (lo + 1u < a.num_streams ? a.page_base[lo + 1u] : running) - a.page_base[lo];
+        if (i + 1u >= np) continue;                                     // the pair straddles two streams
+        const uint8_t* sp = a.in + a.streams[lo].in_offset;
+        StreamInfo si;
+        parse_stream_header(load_u32(sp), load_u32(sp + 4), si);
+        const uint8_t* table = sp + si.header_bytes;
+        const uint32_t o0 = i ? load_u32(table + 4u * i) : 0u, o1 = load_u32(table + 4u * (i + 1u));
+        const uint32_t o2 = i + 2u < np ? load_u32(table + 4u * (i + 2u)) : o1 + load_u32(table);
+        const uint32_t sa = o1 - o0, sb = o2 - o1;
+        const uint32_t big = sa > sb ? sa : sb, small = sa > sb ? sb : sa;
+        ++valid;
+        if ((big - small) * 4u > big) ++differ;
+    }
+    if (valid) atomicAdd(a.status + 3, differ | (valid << 16));
+    wave::global_fence();
+    if (lane == 0u) {
+        const uint32_t packed = a.status[3];
+        a.status[3] = (packed & 0xFFFFu) * 4u > (packed >> 16) ? 1u : 4u;
+    }
 }
 
 // Kernel 2: persistent waves pull page pairs until the counter runs out.
@@ -1282,50 +1410,7 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
     const uint32_t lane = wave::lane_id();
     if (lane < 48u) W.len_code_tab[lane] = kLenCodeTab[lane];
     wave::sync();
-    const uint32_t total = a.page_base[a.num_streams];
-
-    for (;;) {
-        uint32_t g0 = 0;
-        if (lane == 0u) g0 = atomicAdd(a.work_counter, 2u);
-        g0 = wave::bcast(g0, 0);
-        if (g0 >= total) break;                                         // uniform: same value in every lane
-        const uint32_t g = g0 + (lane >> 5);
-
-        PageJob job;
-        job.valid = g < total;
-        job.in = a.in; job.out = a.out; job.in_size = job.out_size = 0; job.in_limit = 0; job.page_size = kMinPageSize;
-        job.page_off = 0; job.dc = nullptr;
-        if (job.valid) {
-            // stream lookup: largest s with page_base[s] <= g
-            uint32_t lo = 0, hi = a.num_streams;
-            while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (a.page_base[mid] <= g) lo = mid; else hi = mid; }
-            const uint32_t i = g - a.page_base[lo];
-            const uint64_t s_in = a.streams[lo].in_offset, s_out = a.streams[lo].out_offset;
-            const uint8_t* sp = a.in + s_in;
-            StreamInfo si;
-            parse_stream_header(load_u32(sp), load_u32(sp + 4), si);
-            const uint8_t* table = sp + si.header_bytes;
-            const uint8_t* pages = table + 4u * si.num_pages;
-            const uint32_t off = i ? load_u32(table + 4u * i) : 0u;                      // src/BrotligDecoder.cpp:310
-            job.in_size = i + 1u < si.num_pages ? load_u32(table + 4u * (i + 1u)) - off : load_u32(table);   // :311
-            job.out_size = (i + 1u == si.num_pages && si.last_page_size) ? si.last_page_size : si.page_size;  // :314
-            job.page_size = si.page_size;
-            job.in = pages + off;
-            const uint64_t abs_in = (uint64_t)(job.in - a.in);
-            const uint64_t room = abs_in < a.in_bytes ? a.in_bytes - abs_in : 0;
-            job.in_limit = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ((room + 3ull) & ~3ull));
-            const uint64_t abs_out = s_out + (uint64_t)i * si.page_size;
-            uint8_t* dst_base = si.preconditioned ? a.scratch : a.out;
-            job.page_off = i * si.page_size;
-            job.dc = si.preconditioned ? &a.dc[lo] : nullptr;
-            job.out = dst_base + abs_out;
-            if (abs_out + job.out_size > a.out_bytes || job.in_size > room || dst_base == nullptr) {
-                job.valid = false;
-                atomicOr(a.status, kStatusBadPage);
-            }
-        }
-        decode_page_pair<kProf>(W, job, a.status, a.prof);
-    }
+    decode_pages<kProf>(W, a);
 }
 
 __global__ void __launch_bounds__(64, 3) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }

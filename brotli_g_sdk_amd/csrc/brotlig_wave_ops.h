@@ -53,6 +53,14 @@ __device__ __forceinline__ uint32_t half_bcast(uint32_t v, uint32_t src)
     return lane_id() < 32u ? a : b;
 }
 
+// The other half's copy of a half-uniform value (two v_readlane).
+__device__ __forceinline__ uint32_t other_half(uint32_t v)
+{
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)v, 32);
+    return lane_id() < 32u ? b : a;
+}
+
 // Inclusive prefix sum over the caller's half.  DPP row shifts cover the 16-lane rows;
 // row_bcast:15 restricted to rows 1 and 3 carries each even row's total into the odd row
 // above it, which closes a 32-lane scan without touching the other half.

@@ -5,14 +5,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from brotli_g_sdk_amd import api
 kind = sys.argv[1] if len(sys.argv) > 1 else "mixed"
-streams, _ = bench.build_streams(kind, range(4), 2048, 128)
+nstreams = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+streams, _ = bench.build_streams(kind, range(nstreams), 2048, 128)
 dec = api.BatchDecoder(streams)
 dec.decode()
 p = dec.phase_profile()
 tot = p["total"]
-out = {k: (v if k in ("rounds", "levels") else round(v / tot, 4)) for k, v in p.items()}
+out = {k: (v if k in ("rounds", "levels", "solo_rounds") else round(v / tot, 4)) for k, v in p.items()}
 out["levels_per_round"] = round(p["levels"] / max(p["rounds"], 1), 2)
 out["cycles_per_round"] = round(tot / max(p["rounds"], 1), 1)
-out["pages"] = sum(2048 for _ in streams)
+out["pages"] = int(sum(api.DecompressedSize(s) for s in streams) // 65536)
 out["workload"] = kind
 print(json.dumps(out))

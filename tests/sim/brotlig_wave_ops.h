@@ -24,6 +24,11 @@ inline uint32_t bcast(uint32_t v, uint32_t src, SIM_SITE)
     const int s = sim::collective_enter(v, 0, site);
     return (uint32_t)sim::g_wave.in_a[s][src & 63u];
 }
+inline uint32_t other_half(uint32_t v, SIM_SITE)
+{
+    const int s = sim::collective_enter(v, 0, site);
+    return (uint32_t)sim::g_wave.in_a[s][lane_id() < 32u ? 32 : 0];
+}
 inline uint32_t half_ballot(bool p, SIM_SITE) { return (uint32_t)(ballot64(p, site) >> (lane_id() & 32u)); }
 inline uint32_t half_shfl(uint32_t v, uint32_t src, SIM_SITE)
 {

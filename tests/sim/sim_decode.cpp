@@ -8,6 +8,7 @@
 
 using namespace brotlig;
 
+static uint32_t g_last_policy = 0;
 static void prepare_body(void* p) { brotlig_prepare_kernel(*(DecodeArgs*)p); }
 static void decode_body(void* p) { brotlig_decode_kernel(*(DecodeArgs*)p); }
 static void decond_body(void* p) { brotlig_decondition_kernel(*(DecodeArgs*)p); }
@@ -31,8 +32,10 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     sim::run_grid(grid ? grid : 4, decode_body, &a);
     sim::run_grid(3, decond_body, &a);
     *status_out = status_words[0];
+    g_last_policy = status_words[3];
     return 0;
 }
 
+extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word 3: pairing policy chosen by the prepare kernel
 extern "C" void sim_selftest(uint32_t* out) { sim::run_grid(1, selftest_body, out); }
 extern "C" uint64_t sim_collectives() { return sim::g_wave.n_collectives; }

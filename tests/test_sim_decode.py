@@ -103,3 +103,16 @@ def test_sim_wave_primitives(sim):
         assert out[lane] == v[base:lane + 1].sum() == out[64 + lane]
         assert out[256 + lane] == v[base:base + 32].max()
         assert out[384 + lane] == v[base + (5 if base else 29)]
+
+
+def test_sim_pairing_policy(sim):
+    """The prepare kernel compares the compressed sizes of neighbouring pages: a stream that mixes page
+    kinds page by page lets the halves of a wavefront run free (threshold 1 quarter), a homogeneous one
+    keeps them in step (4 quarters).  Either way the output is the same."""
+    from brotli_g_sdk_amd import datagen as D
+    sim.sim_last_policy.restype = ctypes.c_uint32
+    for data, want in ((D.mixed(65536 * 24, 5), 1), (D.text(65536 * 8, 6), 4)):
+        stream = E.encode(data)
+        outs, status = run_batch(sim, [stream], [len(data)])
+        assert status == 0 and np.array_equal(outs[0], data)
+        assert sim.sim_last_policy() == want
