@@ -31,7 +31,7 @@ def build_encoder(force=False):
 
 
 def hip_sources():
-    names = ["brotlig_hip.hip", "brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h"]
+    names = ["brotlig_hip.hip", "brotlig_streamer.hip", "brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h"]
     return [os.path.join(CSRC, n) for n in names] + [os.path.join(ROOT, "include", "brotlig_amd.h")]
 
 
@@ -42,7 +42,7 @@ def build_hip(force=False):
     src = hip_sources()
     if force or _stale(HIP_SO, src):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_SO, src[0]]
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_SO, src[0], src[1]]
         subprocess.check_call(cmd, cwd=CSRC)
     return HIP_SO
 

@@ -56,6 +56,18 @@ def lib():
         L.BrotligDeviceSelfTest.restype = ctypes.c_int
         L.BrotligKernelLdsBytes.restype = ctypes.c_uint32
         L.BrotligKernelGridSize.restype = ctypes.c_uint32
+        L.BrotligStreamerCreate.restype = ctypes.c_int
+        L.BrotligStreamerCreate.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                                            ctypes.POINTER(ctypes.c_void_p)]
+        L.BrotligStreamerDestroy.restype = None
+        L.BrotligStreamerDestroy.argtypes = [ctypes.c_void_p]
+        L.BrotligStreamerSubmit.restype = ctypes.c_int
+        L.BrotligStreamerSubmit.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.BrotligStreamerWait.restype = ctypes.c_int
+        L.BrotligStreamerWait.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        L.BrotligStreamerOutput.restype = ctypes.c_void_p
+        L.BrotligStreamerOutput.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
         _lib = L
     return _lib
 
@@ -181,3 +193,69 @@ class BatchDecoder:
 
     def poison_output(self, value=0xCD):
         self.d_out.fill_(value)
+
+
+class Streamer:
+    """Asynchronous host-to-host decoding of batches of streams (BrotligStreamer*, include/brotlig_amd.h):
+    a ring of slots with pinned staging, one hipStream_t each, so that the upload of a batch overlaps
+    the decode of the previous one and the download of the one before.
+
+        st = Streamer(slots=3, slot_in_bytes=64 << 20, slot_out_bytes=256 << 20)
+        t = st.submit(streams)                  # returns at once
+        outs = st.result(t)                     # list of uint8 arrays (copies out of the pinned buffer)
+    """
+
+    def __init__(self, slots=3, slot_in_bytes=64 << 20, slot_out_bytes=256 << 20, max_streams=4096):
+        self._h = ctypes.c_void_p()
+        rc = lib().BrotligStreamerCreate(slots, slot_in_bytes, slot_out_bytes, max_streams, ctypes.byref(self._h))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligStreamerCreate")
+        self._keep = {}
+
+    def close(self):
+        if self._h:
+            lib().BrotligStreamerDestroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, streams, outputs=None):
+        """streams: list of uint8 arrays / bytes.  outputs: optional list of writable uint8 arrays (or None
+        entries) that receive the decoded bytes at wait(); without it the bytes stay in pinned memory."""
+        arrs = [np.ascontiguousarray(np.frombuffer(s, dtype=np.uint8) if not isinstance(s, np.ndarray) else s, dtype=np.uint8)
+                for s in streams]
+        n = len(arrs)
+        ins = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        sizes = (ctypes.c_uint32 * n)(*[a.size for a in arrs])
+        outs = caps = None
+        if outputs is not None:
+            outs = (ctypes.c_void_p * n)(*[(o.ctypes.data if o is not None else None) for o in outputs])
+            caps = (ctypes.c_uint32 * n)(*[(o.size if o is not None else 0) for o in outputs])
+        t = ctypes.c_uint64()
+        rc = lib().BrotligStreamerSubmit(self._h, n, ins, sizes, outs, caps, ctypes.byref(t))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligStreamerSubmit")
+        self._keep[t.value] = (n, outputs)          # the caller's output arrays must outlive the batch
+        return t.value
+
+    def wait(self, ticket):
+        rc = lib().BrotligStreamerWait(self._h, ticket)
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligStreamerWait")
+
+    def result(self, ticket):
+        """Waits for the batch and returns its decoded streams as fresh arrays."""
+        self.wait(ticket)
+        n, _ = self._keep.pop(ticket)
+        out = []
+        for i in range(n):
+            sz = ctypes.c_uint32()
+            p = lib().BrotligStreamerOutput(self._h, ticket, i, ctypes.byref(sz))
+            if not p:
+                raise BrotligError(BROTLIG_ERROR_GENERIC, "BrotligStreamerOutput")
+            out.append(np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(sz.value,)).copy())
+        return out

@@ -29,6 +29,11 @@ struct StreamInfo {
     uint32_t precon_w0, precon_w1;
 };
 
+enum : uint32_t {           // bits of the batch status word (workspace word 0)
+    kStatusBadHeader = 1u,  // magic / id check failed (src/BrotligDecoder.cpp:437-446)
+    kStatusBadPage = 2u,    // a page failed a bounds check (the reference has none: undefined there)
+};
+
 // w0/w1 are the two little-endian dwords of the StreamHeader.
 __host__ __device__ inline bool parse_stream_header(uint32_t w0, uint32_t w1, StreamInfo& s)
 {

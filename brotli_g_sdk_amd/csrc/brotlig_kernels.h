@@ -32,11 +32,6 @@ struct StreamDesc {
     uint64_t out_offset;    // byte offset of its decompressed bytes in the output buffer
 };
 
-enum : uint32_t {           // bits of DecodeArgs::status[0]
-    kStatusBadHeader = 1u,  // magic / id check failed (src/BrotligDecoder.cpp:437-446)
-    kStatusBadPage = 2u,    // a page failed a bounds check (the reference has none: undefined there)
-};
-
 // Per-stream pre-conditioning parameters, derived once per launch by the prepare kernel from the
 // 8-byte PreconditionHeader (inc/DataStream.h:89-98) the way
 // BrotligDataconditionParams::Initialize does (inc/common/BrotligDataConditioner.h:92-237).

@@ -118,6 +118,30 @@ BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in_bytes, voi
                                         void* d_workspace, size_t workspace_bytes, void* d_scratch,
                                         uint64_t* cycles_out, uint32_t n_out);
 
+/* ---- Streaming front end -------------------------------------------------
+ * Host side of the use the shader's stream queue was designed for (`meta` buffer of up to 4096 streams
+ * per launch, src/decoder/BrotliGCompute.hlsl:1757-1881, inc/common/BrotligConstants.h:127-129), which the
+ * reference's sample never exercises: it decodes one stream per synchronous call
+ * (sample/BrotligGPUDecoder.cpp:260-748, called from sample/brotlig_cli.cpp:436-446).
+ * A ring of `num_slots` slots, each with pinned host staging, device buffers and its own hipStream_t:
+ * a submitted batch is uploaded, decoded and downloaded asynchronously, so consecutive batches overlap
+ * (upload k+1 | decode k | download k-1).  One host thread per streamer; no global state.
+ *   slot_in_bytes / slot_out_bytes: capacity of one batch (sum of stream sizes / of NumPages*PageSize).
+ *   Submit copies the streams into pinned memory and returns at once with a ticket (it blocks only
+ *   when every slot is in flight: then the oldest batch is completed first).  outputs[i] may be NULL
+ *   (or `outputs` itself NULL): the decoded bytes then stay in the slot's pinned buffer, readable
+ *   through BrotligStreamerOutput until the slot is reused (num_slots submissions later).
+ *   Wait returns the batch's result (BROTLIG_OK / CORRUPT_STREAM / GENERIC) after copying to outputs[]. */
+typedef struct BrotligStreamer BrotligStreamer;
+BROTLIG_ERROR BrotligStreamerCreate(uint32_t num_slots, uint64_t slot_in_bytes, uint64_t slot_out_bytes,
+                                    uint32_t max_streams_per_batch, BrotligStreamer** out);
+void BrotligStreamerDestroy(BrotligStreamer* streamer);
+BROTLIG_ERROR BrotligStreamerSubmit(BrotligStreamer* streamer, uint32_t num_streams, const uint8_t* const* inputs,
+                                    const uint32_t* input_sizes, uint8_t* const* outputs, const uint32_t* output_caps,
+                                    uint64_t* ticket);
+BROTLIG_ERROR BrotligStreamerWait(BrotligStreamer* streamer, uint64_t ticket);
+const uint8_t* BrotligStreamerOutput(BrotligStreamer* streamer, uint64_t ticket, uint32_t index, uint32_t* size);
+
 /* Static properties, for reports: LDS bytes per workgroup, workgroups launched. */
 uint32_t BrotligKernelLdsBytes(void);
 uint32_t BrotligKernelGridSize(void);

@@ -157,3 +157,47 @@ def test_config4_bc3_texture_stream(api):
     dec.decode()
     for i in range(3):
         assert np.array_equal(dec.output(i), ref)
+
+
+@pytest.mark.gpu
+def test_streamer_overlapped_batches(api):
+    """Streaming front end (include/brotlig_amd.h BrotligStreamer*): batches of mixed plain and
+    pre-conditioned streams go through a 3-slot ring, more batches than slots, results read back both
+    ways (copied to caller buffers, and from the pinned slot); every byte is checked against the oracle."""
+    batches = []
+    for b in range(7):
+        datas = [D.mixed(65536 * 3 + 1000 * b, 100 + b), D.text(40000 + b, 200 + b), D.runs(65536 * 2, 300 + b)]
+        streams = [E.encode(d) for d in datas]
+        tex = D.bc_texture(1 + b % 5, 64, 32, seed=b)
+        streams.append(E.encode(tex, precondition=dict(format=1 + b % 5, width_blocks=64, height_blocks=32, swizzle=True, delta=True)))
+        batches.append(streams)
+    st = api.Streamer(slots=3, slot_in_bytes=4 << 20, slot_out_bytes=8 << 20, max_streams=16)
+    tickets, user = [], []
+    for k, streams in enumerate(batches):
+        outs = None
+        if k % 2 == 0:
+            outs = [np.full(api.DecompressedSize(s), 0xAB, np.uint8) for s in streams]
+        tickets.append(st.submit(streams, outs))
+        user.append(outs)
+        if k >= 2:                                  # stay two batches ahead of the reader
+            j = k - 2
+            _check_batch(st, tickets[j], batches[j], user[j])
+    for j in range(len(batches) - 2, len(batches)):
+        _check_batch(st, tickets[j], batches[j], user[j])
+    with pytest.raises(api.BrotligError):           # a batch larger than a slot is refused, not truncated
+        st.submit([E.encode(D.runs(65536 * 200, 1))])
+    bad = batches[0][0].copy(); bad[1] ^= 0xFF
+    with pytest.raises(api.BrotligError):
+        st.submit([bad])
+    st.close()
+
+
+def _check_batch(st, ticket, streams, user_outs):
+    if user_outs is not None:
+        st.wait(ticket)
+        got = user_outs
+    else:
+        got = st.result(ticket)
+    for s, g in zip(streams, got):
+        rc, ref = oracle_decode(s)
+        assert rc == 0 and np.array_equal(g, ref)
