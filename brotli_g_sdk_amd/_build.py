@@ -47,6 +47,19 @@ def build_hip(force=False):
     return HIP_SO
 
 
+CLI_BIN = os.path.join(ROOT, "tools", "brotlig")
+
+
+def build_cli(force=False):
+    """The portable command-line tool (tools/brotlig_cli.cpp), linked against the two in-tree libraries."""
+    src = os.path.join(ROOT, "tools", "brotlig_cli.cpp")
+    if force or _stale(CLI_BIN, [src, ENC_SO, HIP_SO]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", CLI_BIN, src,
+                               "-L", CSRC, "-lbrotlig_enc", "-lbrotlig_hip", "-Wl,-rpath,$ORIGIN/../brotli_g_sdk_amd/csrc"])
+    return CLI_BIN
+
+
 def build_all(force=False):
     build_encoder(force)
     build_hip(force)
+    build_cli(force)
