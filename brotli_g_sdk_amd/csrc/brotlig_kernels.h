@@ -1364,12 +1364,12 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
     if (lane == 0u) { a.page_base[a.num_streams] = running; a.work_counter[0] = 0u; }
 
     // ---- pairing policy of the decode kernel (decode_pages): do neighbouring pages differ in cost?
-    //      Up to 2048 evenly spaced page pairs (2k, 2k+1) are compared by compressed size; when more
+    //      Up to 1024 evenly spaced page pairs (2k, 2k+1) are compared by compressed size; when more
     //      than a quarter of them differ by over 25 % (a mix of page kinds side by side) the two halves
     //      of a wavefront run free of each other, otherwise they stay in step (status word 3: the number
     //      of quarters of a page within which a free half waits for its neighbour -- 1 or 4).
     wave::global_fence();
-    const uint32_t pairs = running / 2u, nsamp = min_u32(pairs, 2048u);
+    const uint32_t pairs = running / 2u, nsamp = min_u32(pairs, 1024u);
     uint32_t differ = 0, valid = 0;
     for (uint32_t j = lane; j < nsamp; j += 64u) {
         const uint32_t g = 2u * (uint32_t)(((uint64_t)j * pairs) / nsamp);
