@@ -61,6 +61,12 @@ def build_streams(kind, indices, pages_per_stream, distinct):
     for seed in indices:
         if kind == "mixed":
             data = D.mixed(distinct * PAGE, seed)
+        elif kind == "mixed_sorted":
+            # the same pages as "mixed", ordered by compressed size (what a page scheduler that groups
+            # similar pages would present to the kernel); experiment, not a BASELINE config
+            pages = [D.mixed_page(i, seed) for i in range(distinct)]
+            sizes = [len(E.encode(p)) for p in pages]
+            data = np.concatenate([pages[i] for i in np.argsort(sizes, kind="stable")[::-1]])
         elif kind == "runs":
             data = D.runs(distinct * PAGE, seed + 1)
         elif kind == "text":
@@ -119,7 +125,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="mixed", choices=["mixed", "runs", "text", "records", "samples16", "bc3"])
+    ap.add_argument("--workload", default="mixed", choices=["mixed", "mixed_sorted", "runs", "text", "records", "samples16", "bc3"])
     ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--pages-per-stream", type=int, default=4096)
     ap.add_argument("--distinct", type=int, default=256, help="distinct encoded pages per stream (tiled)")

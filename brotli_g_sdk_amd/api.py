@@ -42,6 +42,8 @@ def lib():
                                 ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         L.BrotligDecodeWorkspaceSize.restype = ctypes.c_size_t
         L.BrotligDecodeWorkspaceSize.argtypes = [ctypes.c_uint32]
+        L.BrotligDecodeWorkspaceSizeFor.restype = ctypes.c_size_t
+        L.BrotligDecodeWorkspaceSizeFor.argtypes = [ctypes.c_uint32, ctypes.c_uint64]
         batch = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32,
                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
         L.BrotligDecodeBatchDevice.restype = ctypes.c_int
@@ -101,9 +103,11 @@ def DeviceSelfTest():
 
 class BatchDecoder:
     """Owns the device buffers for a batch of streams and decodes them with one enqueue
-    (BrotligDecodeBatchDevice).  `streams` is a list of uint8 arrays, each one .brotlig stream."""
+    (BrotligDecodeBatchDevice).  `streams` is a list of uint8 arrays, each one .brotlig stream.
+    `schedule=False` sizes the workspace at its minimum, which turns the page schedule off (pages are
+    then decoded in stream order)."""
 
-    def __init__(self, streams, device="cuda:0", out_sizes=None):
+    def __init__(self, streams, device="cuda:0", out_sizes=None, schedule=True):
         import torch
         self.torch = torch
         self.device = torch.device(device)
@@ -136,7 +140,7 @@ class BatchDecoder:
         self.d_desc = torch.from_numpy(desc.view(np.int64)).to(self.device)
         self.d_out = torch.empty(opos + 64, dtype=torch.uint8, device=self.device)
         self.d_scratch = torch.empty(opos + 64, dtype=torch.uint8, device=self.device) if precon else None
-        self.ws_bytes = int(L.BrotligDecodeWorkspaceSize(n))
+        self.ws_bytes = int(L.BrotligDecodeWorkspaceSizeFor(n, opos) if schedule else L.BrotligDecodeWorkspaceSize(n))
         self.d_ws = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
 
     def _args(self, stream):

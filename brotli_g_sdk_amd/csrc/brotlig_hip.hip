@@ -23,14 +23,20 @@ static_assert(sizeof(BrotligStreamDesc) == sizeof(StreamDesc), "descriptor layou
     fprintf(stderr, "brotlig_hip: %s failed: %s\n", #expr, hipGetErrorString(_e)); return BROTLIG_ERROR_GENERIC; } } while (0)
 
 // Device workspace (the reference's `meta` buffer): word 0 status, word 1 page counter, word 2
-// preconditioned-stream count, words 4.. page_base[num_streams + 1], then (1 KiB aligned) one
-// DcTable per stream.
-constexpr size_t kWsHeaderWords = 4;
+// preconditioned-stream count, word 3 pairing policy, words 8..23 scheduling buckets, words 32..
+// page_base[num_streams + 1], then (1 KiB aligned) one DcTable per stream, then -- if the caller's
+// workspace has the room -- the page schedule (one word per page).
+constexpr size_t kWsHeaderWords = 32;
 size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 1023u) & ~(size_t)1023u; }
 size_t workspace_bytes(uint32_t n) { return dc_offset(n) + (size_t)n * sizeof(DcTable); }
+// every page is at least 32 KiB of output, and every stream's output region is whole pages
+uint64_t max_pages(uint32_t n, uint64_t out_bytes) { return out_bytes / kMinPageSize + n; }
+// Below this many pages the schedule is not worth its two extra launches (about two pages per half-wave).
+constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
 
 int g_grid = 0;
 int g_decond_grid = 1024;
+int g_order_grid = 1024;
 
 BROTLIG_ERROR grid_size(int* out)
 {
@@ -42,13 +48,14 @@ BROTLIG_ERROR grid_size(int* out)
         if (per_cu < 1) per_cu = 1;
         g_grid = cus * per_cu;
         g_decond_grid = cus * 8;
+        g_order_grid = cus * 4;
     }
     *out = g_grid;
     return BROTLIG_OK;
 }
 
 DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
-                     const BrotligStreamDesc* d_streams, uint32_t n, void* d_ws, void* d_scratch)
+                     const BrotligStreamDesc* d_streams, uint32_t n, void* d_ws, size_t ws_bytes, void* d_scratch)
 {
     uint32_t* ws = static_cast<uint32_t*>(d_ws);
     DecodeArgs a{};
@@ -58,6 +65,12 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
     a.streams = reinterpret_cast<const StreamDesc*>(d_streams); a.num_streams = n;
     a.status = ws; a.work_counter = ws + 1; a.page_base = ws + kWsHeaderWords;
     a.dc = reinterpret_cast<DcTable*>(static_cast<uint8_t*>(d_ws) + dc_offset(n));
+    const size_t base = workspace_bytes(n);
+    const uint64_t room = ws_bytes > base ? (ws_bytes - base) / 4u : 0u;
+    if (out_bytes >= kOrderMinOutBytes && room >= max_pages(n, out_bytes)) {
+        a.order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_ws) + base);
+        a.order_cap = (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room);
+    }
     return a;
 }
 
@@ -68,6 +81,11 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     if (BROTLIG_ERROR e = grid_size(&grid)) return e;
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), s));
     hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(1), dim3(64), 0, s, a);
+    if (a.order) {                                                      // page schedule: count, then scatter
+        hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g_order_grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g_order_grid), dim3(64), 0, s, a);
+    }
+    hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, s, a);
     if (k0) HIP_OK(hipEventRecord(k0, s));
     hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
     if (k1) HIP_OK(hipEventRecord(k1, s));
@@ -104,6 +122,10 @@ extern "C" uint32_t DecompressedSize(uint8_t* src)
 }
 
 extern "C" size_t BrotligDecodeWorkspaceSize(uint32_t num_streams) { return workspace_bytes(num_streams); }
+extern "C" size_t BrotligDecodeWorkspaceSizeFor(uint32_t num_streams, uint64_t out_bytes)
+{
+    return workspace_bytes(num_streams) + (size_t)(4u * max_pages(num_streams, out_bytes));
+}
 
 extern "C" BROTLIG_ERROR BrotligDecodeBatchDevice(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
                                                   const BrotligStreamDesc* d_streams, uint32_t num_streams,
@@ -111,7 +133,7 @@ extern "C" BROTLIG_ERROR BrotligDecodeBatchDevice(const void* d_in, uint64_t in_
 {
     if (!d_in || !d_out || !d_streams || !d_workspace || num_streams == 0) return BROTLIG_ERROR_GENERIC;
     if (ws_bytes < workspace_bytes(num_streams)) return BROTLIG_ERROR_GENERIC;
-    const DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, d_scratch);
+    const DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, ws_bytes, d_scratch);
     return enqueue(a, static_cast<hipStream_t>(hip_stream), nullptr, nullptr);
 }
 
@@ -132,7 +154,7 @@ extern "C" BROTLIG_ERROR BrotligDecodeBatchTimed(const void* d_in, uint64_t in_b
     if (!d_in || !d_out || !d_streams || !d_workspace || num_streams == 0 || steps == 0) return BROTLIG_ERROR_GENERIC;
     if (ws_bytes < workspace_bytes(num_streams)) return BROTLIG_ERROR_GENERIC;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    const DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, d_scratch);
+    const DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, ws_bytes, d_scratch);
     for (uint32_t i = 0; i < warmup; ++i) if (BROTLIG_ERROR e = enqueue(a, s, nullptr, nullptr)) return e;
     std::vector<hipEvent_t> ev(2 * (size_t)steps + 2);
     for (auto& e : ev) HIP_OK(hipEventCreate(&e));
@@ -170,7 +192,8 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
     HIP_OK(hipMalloc(&d_in.p, in_alloc + 64));
     HIP_OK(hipMalloc(&d_out.p, out_alloc + 64));                        // copies read up to 7 bytes past a page
     if (si.preconditioned) HIP_OK(hipMalloc(&d_scratch.p, out_alloc + 64));
-    HIP_OK(hipMalloc(&d_ws.p, workspace_bytes(1)));
+    const size_t ws_size = BrotligDecodeWorkspaceSizeFor(1, out_alloc);
+    HIP_OK(hipMalloc(&d_ws.p, ws_size));
     HIP_OK(hipMalloc(&d_desc.p, sizeof(BrotligStreamDesc)));
     const BrotligStreamDesc desc{0, 0};
     HIP_OK(hipMemset(static_cast<uint8_t*>(d_in.p) + (in_alloc + 64 - 80), 0, 80));
@@ -180,7 +203,7 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
     hipEvent_t e0, e1;
     HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
     const DecodeArgs a = make_args(d_in.p, input_size, d_out.p, out_alloc, static_cast<BrotligStreamDesc*>(d_desc.p), 1,
-                                   d_ws.p, d_scratch.p);
+                                   d_ws.p, ws_size, d_scratch.p);
     BROTLIG_ERROR err = enqueue(a, nullptr, e0, e1);
     if (err == BROTLIG_OK) err = BrotligDecodeBatchStatus(d_ws.p, nullptr);
     float ms = 0.f;
@@ -193,12 +216,19 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
     return BROTLIG_OK;
 }
 
+static uint32_t mx_other(const uint32_t* v, uint32_t base)     // maximum over the other half's 32 values
+{
+    uint32_t m = 0;
+    for (uint32_t l = base ^ 32u; l < (base ^ 32u) + 32u; ++l) m = v[l] > m ? v[l] : m;
+    return m;
+}
+
 extern "C" BROTLIG_ERROR BrotligDeviceSelfTest(void)
 {
     DevBuf d;
-    HIP_OK(hipMalloc(&d.p, 448 * sizeof(uint32_t)));
+    HIP_OK(hipMalloc(&d.p, 512 * sizeof(uint32_t)));
     hipLaunchKernelGGL(brotlig_selftest_kernel, dim3(1), dim3(64), 0, nullptr, static_cast<uint32_t*>(d.p));
-    uint32_t h[448];
+    uint32_t h[512];
     HIP_OK(hipMemcpy(h, d.p, sizeof h, hipMemcpyDeviceToHost));
     const uint32_t* v = h + 320;
     for (uint32_t lane = 0; lane < 64; ++lane) {
@@ -211,7 +241,7 @@ extern "C" BROTLIG_ERROR BrotligDeviceSelfTest(void)
         }
         if (h[lane] != sum || h[64 + lane] != sum || h[128 + lane] != bal ||
             h[192 + lane] != v[base | ((lane * 7u + 3u) & 31u)] || h[256 + lane] != mx ||
-            h[384 + lane] != v[base | (base ? 5u : 29u)]) {
+            h[384 + lane] != v[base | (base ? 5u : 29u)] || h[448 + lane] != mx_other(v, base)) {
             fprintf(stderr, "brotlig_hip: wave primitive self-test failed at lane %u\n", lane);
             return BROTLIG_ERROR_GENERIC;
         }
@@ -231,10 +261,15 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     DevBuf prof;
     HIP_OK(hipMalloc(&prof.p, kNumPhases * sizeof(unsigned long long)));
     HIP_OK(hipMemset(prof.p, 0, kNumPhases * sizeof(unsigned long long)));
-    DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, d_scratch);
+    DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, ws_bytes, d_scratch);
     a.prof = static_cast<unsigned long long*>(prof.p);
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), nullptr));
     hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(1), dim3(64), 0, nullptr, a);
+    if (a.order) {
+        hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g_order_grid), dim3(64), 0, nullptr, a);
+        hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g_order_grid), dim3(64), 0, nullptr, a);
+    }
+    hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, nullptr, a);
     hipLaunchKernelGGL(brotlig_decode_kernel_timed, dim3(grid), dim3(64), 0, nullptr, a);
     HIP_OK(hipDeviceSynchronize());
     unsigned long long h[kNumPhases];

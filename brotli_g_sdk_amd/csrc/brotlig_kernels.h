@@ -52,7 +52,10 @@ struct DecodeArgs {
     const StreamDesc* streams; uint32_t num_streams;
     uint32_t* page_base;    // [num_streams + 1] exclusive prefix of page counts
     uint32_t* work_counter; // [1] next global page index
-    uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams
+    uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams, [3] pairing policy,
+                            // [8..15] pages per scheduling bucket, [16..23] bucket fill cursors
+    uint32_t* order;        // [order_cap] page schedule: global page indices grouped by bucket (null: page order)
+    uint32_t  order_cap;
     DcTable*  dc;           // [num_streams]
     unsigned long long* prof;   // [kNumPhases] cycle sums, only written by the phase-timer instantiation
 };
@@ -577,13 +580,14 @@ __device__ __forceinline__ uint32_t byte_add(uint32_t x, uint32_t c)
 
 // The job of global page index `g` (meaningful when `ok`): stream lookup, page table walk
 // (src/BrotligDecoder.cpp:310-314), bounds against the caller's buffers.
-__device__ inline PageJob fetch_job(const DecodeArgs& a, uint32_t g, bool ok)
+__device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, uint32_t g, bool ok)
 {
     PageJob job;
     job.valid = ok;
     job.in = a.in; job.out = a.out; job.in_size = job.out_size = 0; job.in_limit = 0; job.page_size = kMinPageSize;
     job.page_off = 0; job.dc = nullptr;
     if (job.valid) {
+        if (order != nullptr) g = order[g];                             // the schedule built by the order kernels
         // stream lookup: largest s with page_base[s] <= g
         uint32_t lo = 0, hi = a.num_streams;
         while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (a.page_base[mid] <= g) lo = mid; else hi = mid; }
@@ -640,7 +644,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
     const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit};
 
     // ---- per-half state of the page under construction
-    PageJob job = fetch_job(a, 0u, false);
+    const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
+    PageJob job = fetch_job(a, order, 0u, false);
     bool live = false;               // inside a compressed page
     bool finished = false;           // the work counter ran out for this half
     uint32_t npostfix = 0, ndirect = 0;
@@ -680,7 +685,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                     const bool got = need && g < total;
                     if (need && !got) { finished = true; need = false; }
                     {
-                        const PageJob nj = fetch_job(a, g, got);
+                        const PageJob nj = fetch_job(a, order, g, got);
                         if (got) job = nj;
                     }
                     const bool fresh = got && job.valid;
@@ -1362,42 +1367,116 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
         running += first_half_total + second_half_total;
     }
     if (lane == 0u) { a.page_base[a.num_streams] = running; a.work_counter[0] = 0u; }
+}
 
-    // ---- pairing policy of the decode kernel (decode_pages): do neighbouring pages differ in cost?
-    //      Up to 1024 evenly spaced page pairs (2k, 2k+1) are compared by compressed size; when more
-    //      than a quarter of them differ by over 25 % (a mix of page kinds side by side) the two halves
-    //      of a wavefront run free of each other, otherwise they stay in step (status word 3: the number
-    //      of quarters of a page within which a free half waits for its neighbour -- 1 or 4).
-    wave::global_fence();
-    const uint32_t pairs = running / 2u, nsamp = min_u32(pairs, 1024u);
+// -------------------------------------------------------------------------------------------
+// Page schedule.  The decode kernel runs two pages per wavefront and pays the maximum of the two in
+// every phase of a round, so it matters which pages meet: the same 4 GiB of mixed pages decode 12 %
+// faster when similar pages are neighbours.  Pages are therefore grouped into eight buckets by
+// compressed size relative to the page size (a factor of two per bucket; stored pages last) and
+// handed out bucket by bucket, dense pages first (they are the slow ones, which also shortens the
+// tail of the launch).  Two passes over the page tables: count, then scatter into `order`.
+
+// compressed and decompressed size of global page g (same walk as fetch_job)
+__device__ inline void page_sizes(const DecodeArgs& a, uint32_t g, uint32_t total, uint32_t& in_size, uint32_t& out_size)
+{
+    uint32_t lo = 0, hi = a.num_streams;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (a.page_base[mid] <= g) lo = mid; else hi = mid; }
+    const uint32_t i = g - a.page_base[lo];
+    const uint32_t np = (lo + 1u < a.num_streams ? a.page_base[lo + 1u] : total) - a.page_base[lo];
+    const uint8_t* sp = a.in + a.streams[lo].in_offset;
+    StreamInfo si;
+    parse_stream_header(load_u32(sp), load_u32(sp + 4), si);
+    const uint8_t* table = sp + si.header_bytes;
+    const uint32_t off = i ? load_u32(table + 4u * i) : 0u;
+    in_size = i + 1u < np ? load_u32(table + 4u * (i + 1u)) - off : load_u32(table);
+    out_size = (i + 1u == np && si.last_page_size) ? si.last_page_size : si.page_size;
+}
+__device__ __forceinline__ uint32_t page_bucket(uint32_t in_size, uint32_t out_size)
+{
+    if (in_size >= out_size) return 7u;                                 // stored (or nonsense): cheapest, last
+    uint32_t b = 0;
+    while (b < 6u && (in_size << (b + 1u)) < out_size) ++b;             // b = floor(log2(out / in)), capped
+    return b;
+}
+constexpr uint32_t kOrderHist = 8, kOrderCursor = 16;                   // status word offsets
+
+__global__ void __launch_bounds__(64) brotlig_order_count_kernel(DecodeArgs a)
+{
+    __shared__ uint32_t hist[8];
+    const uint32_t lane = threadIdx.x, total = a.page_base[a.num_streams];
+    if (a.order == nullptr || total > a.order_cap) return;
+    if (lane < 8u) hist[lane] = 0u;
+    wave::sync();
+    for (uint32_t g = blockIdx.x * 64u + lane; g < total; g += gridDim.x * 64u) {
+        uint32_t in_size, out_size;
+        page_sizes(a, g, total, in_size, out_size);
+        atomicAdd(&hist[page_bucket(in_size, out_size)], 1u);
+    }
+    wave::sync();
+    if (lane < 8u && hist[lane]) atomicAdd(a.status + kOrderHist + lane, hist[lane]);
+}
+
+__global__ void __launch_bounds__(64) brotlig_order_scatter_kernel(DecodeArgs a)
+{
+    __shared__ uint32_t cnt[8], base[8];
+    const uint32_t lane = threadIdx.x, total = a.page_base[a.num_streams];
+    if (a.order == nullptr || total > a.order_cap) return;
+    uint32_t start[8];
+    { uint32_t run = 0; for (uint32_t b = 0; b < 8u; ++b) { start[b] = run; run += a.status[kOrderHist + b]; } }
+    for (uint32_t g0 = blockIdx.x * 64u; g0 < total; g0 += gridDim.x * 64u) {      // uniform trip count
+        const uint32_t g = g0 + lane;
+        if (lane < 8u) cnt[lane] = 0u;
+        wave::sync();
+        uint32_t b = 0, rank = 0;
+        if (g < total) {
+            uint32_t in_size, out_size;
+            page_sizes(a, g, total, in_size, out_size);
+            b = page_bucket(in_size, out_size);
+            rank = atomicAdd(&cnt[b], 1u);
+        }
+        wave::sync();
+        if (lane < 8u) base[lane] = cnt[lane] ? atomicAdd(a.status + kOrderCursor + lane, cnt[lane]) : 0u;
+        wave::sync();
+        if (g < total) {
+            uint32_t s0 = 0;
+            for (uint32_t k = 0; k < 8u; ++k) s0 = k == b ? start[k] : s0;
+            a.order[s0 + base[b] + rank] = g;
+        }
+        wave::sync();
+    }
+}
+
+// Pairing policy of the decode kernel (decode_pages): do neighbouring pages of the schedule differ in
+// cost?  Up to 1024 evenly spaced pairs (2k, 2k+1) are compared by compressed size; when more than a
+// quarter of them differ by over 25 % (page kinds side by side) the two halves of a wavefront run free
+// of each other, otherwise they stay in step (status word 3: the number of quarters of a page within
+// which a free half waits for its neighbour -- 1 or 4).  One workgroup, after the order kernels.
+__global__ void __launch_bounds__(64) brotlig_policy_kernel(DecodeArgs a)
+{
+    const uint32_t lane = threadIdx.x, total = a.page_base[a.num_streams];
+    const bool ordered = a.order != nullptr && total <= a.order_cap;
+    const uint32_t pairs = total / 2u, nsamp = min_u32(pairs, 1024u);
     uint32_t differ = 0, valid = 0;
     for (uint32_t j = lane; j < nsamp; j += 64u) {
         const uint32_t g = 2u * (uint32_t)(((uint64_t)j * pairs) / nsamp);
-        uint32_t lo = 0, hi = a.num_streams;
-        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (a.page_base[mid] <= g) lo = mid; else hi = mid; }
-        const uint32_t i = g - a.page_base[lo];
-        const uint32_t np = (lo + 1u < a.num_streams ? a.page_base[lo + 1u] : running) - a.page_base[lo];
-        if (i + 1u >= np) continue;                                     // the pair straddles two streams
-        const uint8_t* sp = a.in + a.streams[lo].in_offset;
-        StreamInfo si;
-        parse_stream_header(load_u32(sp), load_u32(sp + 4), si);
-        const uint8_t* table = sp + si.header_bytes;
-        const uint32_t o0 = i ? load_u32(table + 4u * i) : 0u, o1 = load_u32(table + 4u * (i + 1u));
-        const uint32_t o2 = i + 2u < np ? load_u32(table + 4u * (i + 2u)) : o1 + load_u32(table);
-        const uint32_t sa = o1 - o0, sb = o2 - o1;
+        uint32_t sa, ua, sb, ub;
+        page_sizes(a, ordered ? a.order[g] : g, total, sa, ua);
+        page_sizes(a, ordered ? a.order[g + 1u] : g + 1u, total, sb, ub);
         const uint32_t big = sa > sb ? sa : sb, small = sa > sb ? sb : sa;
         ++valid;
         if ((big - small) * 4u > big) ++differ;
     }
     if (valid) atomicAdd(a.status + 3, differ | (valid << 16));
     wave::global_fence();
+    wave::sync();
     if (lane == 0u) {
         const uint32_t packed = a.status[3];
         a.status[3] = (packed & 0xFFFFu) * 4u > (packed >> 16) ? 1u : 4u;
     }
 }
 
-// Kernel 2: persistent waves pull page pairs until the counter runs out.
+// Kernel 2: persistent waves; each half pulls pages until the counter runs out (decode_pages).
 template <bool kProf>
 __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
 {
@@ -1423,6 +1502,7 @@ __global__ void __launch_bounds__(64) brotlig_selftest_kernel(uint32_t* out)
     out[192 + lane] = wave::half_shfl(v, lane * 7u + 3u);
     out[384 + lane] = wave::half_bcast(v, (lane & 32u) ? 5u : 29u);    // source lane uniform within each half
     out[256 + lane] = wave::half_max(v);
+    out[448 + lane] = wave::other_half(wave::half_max(v));            // a half-uniform value, seen from the other half
     out[320 + lane] = v;
 }
 

@@ -113,7 +113,7 @@ extern "C" BROTLIG_ERROR BrotligStreamerCreate(uint32_t num_slots, uint64_t slot
     st->slot_in = align_up(slot_in_bytes, kAlign) + kAlign * max_streams_per_batch;     // per-stream alignment padding
     st->slot_out = align_up(slot_out_bytes, kAlign) + kAlign * max_streams_per_batch;
     st->max_streams = max_streams_per_batch;
-    st->ws_bytes = BrotligDecodeWorkspaceSize(max_streams_per_batch);
+    st->ws_bytes = BrotligDecodeWorkspaceSizeFor(max_streams_per_batch, st->slot_out);
     st->slots.resize(num_slots);
     const uint64_t desc_bytes = sizeof(BrotligStreamDesc) * (uint64_t)max_streams_per_batch;
     for (Slot& s : st->slots) {

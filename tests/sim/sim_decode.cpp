@@ -9,7 +9,11 @@
 using namespace brotlig;
 
 static uint32_t g_last_policy = 0;
+static int g_use_order = 1;      // page schedule on (the GPU host code only uses it for large batches)
 static void prepare_body(void* p) { brotlig_prepare_kernel(*(DecodeArgs*)p); }
+static void order_count_body(void* p) { brotlig_order_count_kernel(*(DecodeArgs*)p); }
+static void order_scatter_body(void* p) { brotlig_order_scatter_kernel(*(DecodeArgs*)p); }
+static void policy_body(void* p) { brotlig_policy_kernel(*(DecodeArgs*)p); }
 static void decode_body(void* p) { brotlig_decode_kernel(*(DecodeArgs*)p); }
 static void decond_body(void* p) { brotlig_decondition_kernel(*(DecodeArgs*)p); }
 static void selftest_body(void* p) { brotlig_selftest_kernel((uint32_t*)p); }
@@ -22,13 +26,17 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     for (uint32_t i = 0; i < num_streams; ++i) { sd[i].in_offset = in_offsets[i]; sd[i].out_offset = out_offsets[i]; }
     std::vector<uint32_t> page_base(num_streams + 1, 0);
     uint32_t counter = 0;
-    uint32_t status_words[4] = {0, 0, 0, 0};
+    uint32_t status_words[32] = {0};
     std::vector<DcTable> dc(num_streams);
     DecodeArgs a{};
     a.in = in; a.in_bytes = in_bytes; a.out = out; a.out_bytes = out_bytes; a.scratch = scratch;
     a.streams = sd.data(); a.num_streams = num_streams;
     a.page_base = page_base.data(); a.work_counter = &counter; a.status = status_words; a.dc = dc.data();
+    std::vector<uint32_t> order(g_use_order ? (size_t)(out_bytes / 32768 + num_streams + 1) : 0);
+    if (g_use_order) { a.order = order.data(); a.order_cap = (uint32_t)order.size(); }
     sim::run_grid(1, prepare_body, &a);
+    if (a.order) { sim::run_grid(3, order_count_body, &a); sim::run_grid(3, order_scatter_body, &a); }
+    sim::run_grid(1, policy_body, &a);
     sim::run_grid(grid ? grid : 4, decode_body, &a);
     sim::run_grid(3, decond_body, &a);
     *status_out = status_words[0];
@@ -37,5 +45,6 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
 }
 
 extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word 3: pairing policy chosen by the prepare kernel
+extern "C" void sim_set_order(int on) { g_use_order = on; }
 extern "C" void sim_selftest(uint32_t* out) { sim::run_grid(1, selftest_body, out); }
 extern "C" uint64_t sim_collectives() { return sim::g_wave.n_collectives; }

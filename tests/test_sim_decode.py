@@ -95,7 +95,7 @@ def test_sim_bad_header_sets_status(sim):
 
 
 def test_sim_wave_primitives(sim):
-    out = np.zeros(448, np.uint32)
+    out = np.zeros(512, np.uint32)
     sim.sim_selftest(out.ctypes.data)
     v = out[320:384]
     for lane in range(64):
@@ -103,6 +103,7 @@ def test_sim_wave_primitives(sim):
         assert out[lane] == v[base:lane + 1].sum() == out[64 + lane]
         assert out[256 + lane] == v[base:base + 32].max()
         assert out[384 + lane] == v[base + (5 if base else 29)]
+        assert out[448 + lane] == v[(base ^ 32):(base ^ 32) + 32].max()
 
 
 def test_sim_pairing_policy(sim):
@@ -116,3 +117,25 @@ def test_sim_pairing_policy(sim):
         outs, status = run_batch(sim, [stream], [len(data)])
         assert status == 0 and np.array_equal(outs[0], data)
         assert sim.sim_last_policy() == want
+
+
+def test_sim_page_schedule_on_and_off(sim):
+    """The page schedule (order kernels: pages grouped into size buckets, dense first) only changes which
+    half-wave decodes which page; the output is identical with and without it, for plain and
+    pre-conditioned streams in one batch."""
+    from brotli_g_sdk_amd import datagen as D
+    datas = [D.mixed(65536 * 9 + 4321, 11), D.runs(65536 * 3, 12), D.random_bytes(65536 * 2 + 17, 13)]
+    streams = [E.encode(d) for d in datas]
+    tex = D.bc_texture(3, 64, 48, seed=14)
+    streams.append(E.encode(tex, precondition=dict(format=3, width_blocks=64, height_blocks=48, swizzle=True, delta=True)))
+    datas.append(tex)
+    sim.sim_set_order.argtypes = [ctypes.c_int]
+    try:
+        for on in (0, 1):
+            sim.sim_set_order(on)
+            outs, status = run_batch(sim, streams, [len(d) for d in datas], precon=True)
+            assert status == 0
+            for o, d in zip(outs, datas):
+                assert np.array_equal(o, d)
+    finally:
+        sim.sim_set_order(1)
