@@ -1448,7 +1448,7 @@ __global__ void __launch_bounds__(64) brotlig_order_scatter_kernel(DecodeArgs a)
 }
 
 // Pairing policy of the decode kernel (decode_pages): do neighbouring pages of the schedule differ in
-// cost?  Up to 1024 evenly spaced pairs (2k, 2k+1) are compared by compressed size; when more than a
+// cost?  Up to 256 evenly spaced pairs (2k, 2k+1) are compared by compressed size; when more than a
 // quarter of them differ by over 25 % (page kinds side by side) the two halves of a wavefront run free
 // of each other, otherwise they stay in step (status word 3: the number of quarters of a page within
 // which a free half waits for its neighbour -- 1 or 4).  One workgroup, after the order kernels.
@@ -1456,7 +1456,7 @@ __global__ void __launch_bounds__(64) brotlig_policy_kernel(DecodeArgs a)
 {
     const uint32_t lane = threadIdx.x, total = a.page_base[a.num_streams];
     const bool ordered = a.order != nullptr && total <= a.order_cap;
-    const uint32_t pairs = total / 2u, nsamp = min_u32(pairs, 1024u);
+    const uint32_t pairs = total / 2u, nsamp = min_u32(pairs, 256u);
     uint32_t differ = 0, valid = 0;
     for (uint32_t j = lane; j < nsamp; j += 64u) {
         const uint32_t g = 2u * (uint32_t)(((uint64_t)j * pairs) / nsamp);
