@@ -201,3 +201,27 @@ def _check_batch(st, ticket, streams, user_outs):
     for s, g in zip(streams, got):
         rc, ref = oracle_decode(s)
         assert rc == 0 and np.array_equal(g, ref)
+
+
+@pytest.mark.gpu
+def test_page_schedule_large_batch(api):
+    """Batches of 768 MiB and more are decoded through the page schedule (pages grouped into size buckets,
+    dense first: include/brotlig_amd.h BrotligDecodeWorkspaceSizeFor).  1 GiB of four different page kinds
+    plus a pre-conditioned texture: the output is the same with the schedule and without it (minimum
+    workspace), and equals the bytes the streams were made from."""
+    kinds = [D.mixed(128 * 65536, 21), D.runs(128 * 65536, 22), D.text(128 * 65536, 23), D.records(128 * 65536, 24)]
+    streams = [D.tile_stream(E.encode(d), 32) for d in kinds]           # 4 x 4096 pages = 1 GiB
+    tex = D.bc_texture(3, 128, 128, seed=25)
+    streams.append(E.encode(tex, precondition=dict(format=3, width_blocks=128, height_blocks=128, swizzle=True, delta=True)))
+    sizes = [32 * len(d) for d in kinds] + [len(tex)]
+    outs = []
+    for schedule in (True, False):
+        dec = api.BatchDecoder(streams, out_sizes=sizes, schedule=schedule)
+        dec.poison_output()
+        dec.decode()
+        outs.append([dec.output(i) for i in range(len(streams))])
+        del dec
+    for i, d in enumerate(kinds):
+        assert np.array_equal(outs[0][i].reshape(32, -1), np.broadcast_to(d, (32, len(d))))
+        assert np.array_equal(outs[0][i], outs[1][i])
+    assert np.array_equal(outs[0][4], tex) and np.array_equal(outs[1][4], tex)
