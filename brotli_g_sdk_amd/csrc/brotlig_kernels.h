@@ -41,7 +41,8 @@ struct DcTable {
     uint32_t w[kMaxMips], h[kMaxMips], pitch[kMaxMips];
     uint32_t mip_off_bytes[kMaxMips + 1], mip_off_blocks[kMaxMips + 1];
     uint32_t item_prefix[kMaxMips + 1];     // de-conditioning work items (2 x 32 tiles of row chunks, 64 each) before each mip
-    uint32_t pad[34];
+    uint32_t format;                        // 1..5 = BC1..BC5, 0 = unknown (one byte per block)
+    uint32_t pad[33];
 };
 static_assert(sizeof(DcTable) == 1024, "DcTable is addressed as 1 KiB records");
 
@@ -1228,6 +1229,7 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
     const uint32_t bb = (fmt == 1u || fmt == 4u) ? 8u : (fmt == 0u || fmt > 5u) ? 1u : 16u;
     const uint32_t px = (fmt >= 1u && fmt <= 5u) ? 4u : 1u;
     const bool aligned = ((w0 >> 1) & 1u) != 0u;
+    t.format = (fmt >= 1u && fmt <= 5u) ? fmt : 0u;
     t.precon = 1; t.swizzle = w0 & 1u; t.block_bytes = bb; t.num_sub = nsub; t.color_mask = color;
     t.num_mips = ((w1 >> 8) & 0x1Fu) + 1u;
     uint32_t off = 0;
@@ -1284,6 +1286,26 @@ __device__ __forceinline__ uint64_t dc_load_sub(const uint8_t* src, uint32_t sz)
     return v;
 }
 
+// All sub-blocks of one block (kSizes: their sizes, four bits each, first sub-block lowest -- dc_init).
+template <uint32_t kSizes, uint32_t kNumSub>
+__device__ __forceinline__ void dc_gather_block(const uint8_t* cond, const DcTable& t, uint32_t gblock, uint64_t& lo, uint64_t& hi)
+{
+    uint64_t v[kNumSub];
+#pragma unroll
+    for (uint32_t sub = 0; sub < kNumSub; ++sub) {
+        const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
+        v[sub] = dc_load_sub(cond + t.sub_stream_off[sub] + gblock * sz, sz);
+    }
+    uint32_t off = 0;
+#pragma unroll
+    for (uint32_t sub = 0; sub < kNumSub; ++sub) {
+        const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
+        if (off < 8u) { lo |= v[sub] << (8u * off); if (off + sz > 8u) hi |= v[sub] >> (8u * (8u - off)); }
+        else hi |= v[sub] << (8u * (off - 8u));
+        off += sz;
+    }
+}
+
 __global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
 {
     if (a.status[2] == 0u) return;                                      // no preconditioned stream in this batch
@@ -1296,13 +1318,20 @@ __global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
         const uint8_t* cond = a.scratch + base;
         uint8_t* tex = a.out + base;
         const uint32_t bb = t.block_bytes, items = t.item_prefix[t.num_mips];
-        for (uint32_t item = tid; item < items; item += nthreads) {
+        // Streams decoded side by side (blockIdx.y) start at different tiles: textures of the same size sit
+        // at power-of-two distances in memory, and walking them in step would hit the same HBM channels.
+        const uint32_t ntiles = items >> 6;
+        const uint32_t rot = ntiles ? ((s * 2654435761u) >> 8) % ntiles * 64u : 0u;
+        for (uint32_t item0 = tid; item0 < items; item0 += nthreads) {
+            const uint32_t item = item0 + rot < items ? item0 + rot : item0 + rot - items;
+            // a wavefront owns one tile (64 consecutive items; nthreads is a multiple of 64): the mip and tile
+            // coordinates are wave-uniform and go to the scalar unit
+            const uint32_t tile_item = wave::uniform(item & ~63u), l = item & 63u;
             uint32_t m = 0;
-            while (item >= t.item_prefix[m + 1]) ++m;
+            while (tile_item >= t.item_prefix[m + 1]) ++m;
             const uint32_t W = t.w[m], H = t.h[m], pitch = t.pitch[m];
             const uint32_t per_row = (pitch + bb - 1u) / bb, tiles_x = (per_row + 31u) / 32u;
-            const uint32_t in_mip = item - t.item_prefix[m];
-            const uint32_t tile = in_mip >> 6, l = in_mip & 63u;
+            const uint32_t tile = (tile_item - t.item_prefix[m]) >> 6;
             const uint32_t tr = tile / tiles_x, tc = tile - tr * tiles_x;
             const uint32_t row = 2u * tr + ((l >> 1) & 1u), col = 32u * tc + 2u * (l >> 2) + (l & 1u);
             if (row >= H || col >= per_row) continue;
@@ -1314,14 +1343,22 @@ __global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
                 uint32_t block = row * W + col;
                 const uint32_t effW = W - (W & 1u), effH = H - (H & 1u);
                 if (t.swizzle && W >= 2u && H >= 2u && row < effH && col < effW) {
-                    const uint32_t eff = ((row >> 1) * (effW >> 1) + (col >> 1)) * 4u + (row & 1u) * 2u + (col & 1u);
-                    block = (eff / effW) * W + eff % effW;
+                    // eff = (row / 2) * 2 effW + x with x = 4 (col / 2) + 2 (row & 1) + (col & 1) < 2 effW,
+                    // so eff / effW and eff % effW need one compare, not a division
+                    const uint32_t x = (col >> 1) * 4u + (row & 1u) * 2u + (col & 1u);
+                    const uint32_t wrap = x >= effW ? 1u : 0u;
+                    block = (2u * (row >> 1) + wrap) * W + (x - (wrap ? effW : 0u));
                 }
-                for (uint32_t sub = 0; sub < t.num_sub; ++sub) {
-                    const uint32_t sz = t.sub_size[sub], off = t.sub_off[sub];
-                    const uint64_t v = dc_load_sub(cond + t.sub_stream_off[sub] + (t.mip_off_blocks[m] + block) * sz, sz);
-                    if (off < 8u) { lo |= v << (8u * off); if (off + sz > 8u) hi |= v >> (8u * (8u - off)); }
-                    else hi |= v << (8u * (off - 8u));
+                const uint32_t gblock = t.mip_off_blocks[m] + block;
+                // per-format instantiations: sub-block sizes known at compile time, so that all of a block's
+                // loads are issued back to back and waited for once
+                switch (t.format) {
+                case 1: dc_gather_block<0x422u, 3u>(cond, t, gblock, lo, hi); break;
+                case 2: dc_gather_block<0x4228u, 4u>(cond, t, gblock, lo, hi); break;
+                case 3: dc_gather_block<0x422611u, 6u>(cond, t, gblock, lo, hi); break;
+                case 4: dc_gather_block<0x611u, 3u>(cond, t, gblock, lo, hi); break;
+                case 5: dc_gather_block<0x611611u, 6u>(cond, t, gblock, lo, hi); break;
+                default: dc_gather_block<0x1u, 1u>(cond, t, gblock, lo, hi); break;
                 }
             }
             const bool aligned = ((uint64_t)(uintptr_t)dst & (uint64_t)(bb - 1u)) == 0u;

@@ -53,6 +53,9 @@ __device__ __forceinline__ uint32_t half_bcast(uint32_t v, uint32_t src)
     return lane_id() < 32u ? a : b;
 }
 
+// A value the caller knows to be the same in every lane, moved to a scalar register.
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // The other half's copy of a half-uniform value (two v_readlane).
 __device__ __forceinline__ uint32_t other_half(uint32_t v)
 {

@@ -24,6 +24,7 @@ inline uint32_t bcast(uint32_t v, uint32_t src, SIM_SITE)
     const int s = sim::collective_enter(v, 0, site);
     return (uint32_t)sim::g_wave.in_a[s][src & 63u];
 }
+inline uint32_t uniform(uint32_t v) { return v; }
 inline uint32_t other_half(uint32_t v, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);
