@@ -87,7 +87,8 @@ template <> struct PhaseClock<true> {
 constexpr int kLutBitsIcp = 8;
 constexpr int kLutBitsDist = 8;
 constexpr int kLutBitsLit = 8;
-constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index
+constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
+constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
 constexpr uint32_t kShortCopy = 32;         // copies up to this length run one-lane-per-command
 // Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
@@ -374,8 +375,15 @@ __device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitRe
     static_assert(kBits >= 7 && kBits <= 14, "limit words 8..15 must cover every long length");
     const uint32_t bits = (uint32_t)br.buf;
     const uint32_t e = t.lut[bits & ((1u << kBits) - 1u)];
-    if (e != kLongCode) { len = e & 15u; return e >> 4; }
-    const uint32_t v = __brev(bits) >> 17;                      // next 15 bits, MSB-first
+    if (e < kLutSubtree) { len = e & 15u; return e >> 4; }
+    const uint32_t rb = __brev(bits);                           // stream bits, first bit on top
+    if (e != kLongCode) {                                       // all codes under this prefix share one length
+        const uint32_t l = e & 15u;
+        const uint32_t idx = ((e >> 4) & 0x3FFu) + ((rb >> (32u - l)) & ((1u << (l - (uint32_t)kBits)) - 1u));
+        len = l;
+        return table_sym(t, idx);
+    }
+    const uint32_t v = rb >> 17;                                // next 15 bits, MSB-first
     uint32_t lim[4];
     __builtin_memcpy(lim, t.limit + 8, 16);                     // limits of lengths 8..15, two per word
     uint32_t l = (uint32_t)kBits + 1u;
@@ -510,16 +518,33 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         wave::sync();
         // primary LUT, one entry per lane per step
         if (is_complex) {
+            uint32_t lim[8];                                       // limits of lengths 0..15, two per word
+            __builtin_memcpy(lim, t.limit, 32);
+            // length of the code whose left-justified 15-bit value range contains v (16: none)
+            auto length_of = [&lim](uint32_t v) {
+                uint32_t l = 1;
+#pragma unroll
+                for (int k = 1; k < 16; ++k) {
+                    const uint32_t w = lim[k >> 1];
+                    l += v >= ((k & 1) ? (w >> 16) : (w & 0xFFFFu)) ? 1u : 0u;
+                }
+                return l;
+            };
             for (uint32_t e = sl; e < lut_size; e += 32u) {
                 const uint32_t v = __brev(e) >> 17;                // LUT index bits as a left-justified 15-bit code prefix
-                uint32_t l = 1;
-                while (l <= (uint32_t)t.lut_bits && v >= t.limit[l]) ++l;
+                const uint32_t l = length_of(v);
                 uint32_t entry = kLongCode;
-                if (l <= (uint32_t)t.lut_bits) {
+                if (l <= 15u) {
                     const uint32_t fo = t.first_offs[l];
-                    uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
-                    idx = min_u32(idx, A - 1u);
-                    entry = (table_sym(t, idx) << 4) | l;
+                    const uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
+                    if (l <= (uint32_t)t.lut_bits) {
+                        entry = (table_sym(t, min_u32(idx, A - 1u)) << 4) | l;
+                    } else if (length_of(v + (1u << (15u - (uint32_t)t.lut_bits)) - 1u) == l &&
+                               idx + (1u << (l - (uint32_t)t.lut_bits)) <= A) {
+                        // every code under this prefix has length l: they are consecutive in code order, so the
+                        // symbol is sorted[idx + the next l - lut_bits code bits] -- no length search at decode time
+                        entry = kLutSubtree | (idx << 4) | l;
+                    }
                 }
                 t.lut[e] = (uint16_t)entry;
             }
