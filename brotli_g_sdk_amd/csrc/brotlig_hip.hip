@@ -23,10 +23,10 @@ static_assert(sizeof(BrotligStreamDesc) == sizeof(StreamDesc), "descriptor layou
     fprintf(stderr, "brotlig_hip: %s failed: %s\n", #expr, hipGetErrorString(_e)); return BROTLIG_ERROR_GENERIC; } } while (0)
 
 // Device workspace (the reference's `meta` buffer): word 0 status, word 1 page counter, word 2
-// preconditioned-stream count, word 3 pairing policy, words 8..23 scheduling buckets, words 32..
+// preconditioned-stream count, word 3 pairing policy, words 8..39 scheduling buckets, words 64..
 // page_base[num_streams + 1], then (1 KiB aligned) one DcTable per stream, then -- if the caller's
 // workspace has the room -- the page schedule (one word per page).
-constexpr size_t kWsHeaderWords = 32;
+constexpr size_t kWsHeaderWords = 64;
 size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 1023u) & ~(size_t)1023u; }
 size_t workspace_bytes(uint32_t n) { return dc_offset(n) + (size_t)n * sizeof(DcTable); }
 // every page is at least 32 KiB of output, and every stream's output region is whole pages

@@ -54,7 +54,7 @@ struct DecodeArgs {
     uint32_t* page_base;    // [num_streams + 1] exclusive prefix of page counts
     uint32_t* work_counter; // [1] next global page index
     uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams, [3] pairing policy,
-                            // [8..15] pages per scheduling bucket, [16..23] bucket fill cursors
+                            // [8..23] pages per scheduling bucket, [24..39] bucket fill cursors
     uint32_t* order;        // [order_cap] page schedule: global page indices grouped by bucket (null: page order)
     uint32_t  order_cap;
     DcTable*  dc;           // [num_streams]
@@ -1434,8 +1434,8 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
 // -------------------------------------------------------------------------------------------
 // Page schedule.  The decode kernel runs two pages per wavefront and pays the maximum of the two in
 // every phase of a round, so it matters which pages meet: the same 4 GiB of mixed pages decode 12 %
-// faster when similar pages are neighbours.  Pages are therefore grouped into eight buckets by
-// compressed size relative to the page size (a factor of two per bucket; stored pages last) and
+// faster when similar pages are neighbours.  Pages are therefore grouped into sixteen buckets by
+// compressed size relative to the page size (half an octave per bucket; stored pages last) and
 // handed out bucket by bucket, dense pages first (they are the slow ones, which also shortens the
 // tail of the launch).  Two passes over the page tables: count, then scatter into `order`.
 
@@ -1454,21 +1454,23 @@ __device__ inline void page_sizes(const DecodeArgs& a, uint32_t g, uint32_t tota
     in_size = i + 1u < np ? load_u32(table + 4u * (i + 1u)) - off : load_u32(table);
     out_size = (i + 1u == np && si.last_page_size) ? si.last_page_size : si.page_size;
 }
+constexpr uint32_t kBuckets = 16;
 __device__ __forceinline__ uint32_t page_bucket(uint32_t in_size, uint32_t out_size)
 {
-    if (in_size >= out_size) return 7u;                                 // stored (or nonsense): cheapest, last
-    uint32_t b = 0;
-    while (b < 6u && (in_size << (b + 1u)) < out_size) ++b;             // b = floor(log2(out / in)), capped
+    if (in_size >= out_size) return kBuckets - 1u;                      // stored (or nonsense): cheapest, last
+    // half-octave steps of out / in: bucket b holds in_size in (out / 2^((b+1)/2), out / 2^(b/2)]
+    uint32_t b = 0, t = (out_size * 181u) >> 8;                          // 181/256 ~ 1/sqrt(2); out_size <= 128 KiB
+    while (b < kBuckets - 2u && in_size <= t) { ++b; t = (t * 181u) >> 8; }
     return b;
 }
-constexpr uint32_t kOrderHist = 8, kOrderCursor = 16;                   // status word offsets
+constexpr uint32_t kOrderHist = 8, kOrderCursor = 8 + kBuckets;         // status word offsets
 
 __global__ void __launch_bounds__(64) brotlig_order_count_kernel(DecodeArgs a)
 {
-    __shared__ uint32_t hist[8];
+    __shared__ uint32_t hist[kBuckets];
     const uint32_t lane = threadIdx.x, total = a.page_base[a.num_streams];
     if (a.order == nullptr || total > a.order_cap) return;
-    if (lane < 8u) hist[lane] = 0u;
+    if (lane < kBuckets) hist[lane] = 0u;
     wave::sync();
     for (uint32_t g = blockIdx.x * 64u + lane; g < total; g += gridDim.x * 64u) {
         uint32_t in_size, out_size;
@@ -1476,19 +1478,19 @@ __global__ void __launch_bounds__(64) brotlig_order_count_kernel(DecodeArgs a)
         atomicAdd(&hist[page_bucket(in_size, out_size)], 1u);
     }
     wave::sync();
-    if (lane < 8u && hist[lane]) atomicAdd(a.status + kOrderHist + lane, hist[lane]);
+    if (lane < kBuckets && hist[lane]) atomicAdd(a.status + kOrderHist + lane, hist[lane]);
 }
 
 __global__ void __launch_bounds__(64) brotlig_order_scatter_kernel(DecodeArgs a)
 {
-    __shared__ uint32_t cnt[8], base[8];
+    __shared__ uint32_t cnt[kBuckets], base[kBuckets];
     const uint32_t lane = threadIdx.x, total = a.page_base[a.num_streams];
     if (a.order == nullptr || total > a.order_cap) return;
-    uint32_t start[8];
-    { uint32_t run = 0; for (uint32_t b = 0; b < 8u; ++b) { start[b] = run; run += a.status[kOrderHist + b]; } }
+    uint32_t start[kBuckets];
+    { uint32_t run = 0; for (uint32_t b = 0; b < kBuckets; ++b) { start[b] = run; run += a.status[kOrderHist + b]; } }
     for (uint32_t g0 = blockIdx.x * 64u; g0 < total; g0 += gridDim.x * 64u) {      // uniform trip count
         const uint32_t g = g0 + lane;
-        if (lane < 8u) cnt[lane] = 0u;
+        if (lane < kBuckets) cnt[lane] = 0u;
         wave::sync();
         uint32_t b = 0, rank = 0;
         if (g < total) {
@@ -1498,11 +1500,11 @@ __global__ void __launch_bounds__(64) brotlig_order_scatter_kernel(DecodeArgs a)
             rank = atomicAdd(&cnt[b], 1u);
         }
         wave::sync();
-        if (lane < 8u) base[lane] = cnt[lane] ? atomicAdd(a.status + kOrderCursor + lane, cnt[lane]) : 0u;
+        if (lane < kBuckets) base[lane] = cnt[lane] ? atomicAdd(a.status + kOrderCursor + lane, cnt[lane]) : 0u;
         wave::sync();
         if (g < total) {
             uint32_t s0 = 0;
-            for (uint32_t k = 0; k < 8u; ++k) s0 = k == b ? start[k] : s0;
+            for (uint32_t k = 0; k < kBuckets; ++k) s0 = k == b ? start[k] : s0;
             a.order[s0 + base[b] + rank] = g;
         }
         wave::sync();

@@ -26,7 +26,7 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     for (uint32_t i = 0; i < num_streams; ++i) { sd[i].in_offset = in_offsets[i]; sd[i].out_offset = out_offsets[i]; }
     std::vector<uint32_t> page_base(num_streams + 1, 0);
     uint32_t counter = 0;
-    uint32_t status_words[32] = {0};
+    uint32_t status_words[64] = {0};
     std::vector<DcTable> dc(num_streams);
     DecodeArgs a{};
     a.in = in; a.in_bytes = in_bytes; a.out = out; a.out_bytes = out_bytes; a.scratch = scratch;

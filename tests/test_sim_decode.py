@@ -112,11 +112,18 @@ def test_sim_pairing_policy(sim):
     keeps them in step (4 quarters).  Either way the output is the same."""
     from brotli_g_sdk_amd import datagen as D
     sim.sim_last_policy.restype = ctypes.c_uint32
-    for data, want in ((D.mixed(65536 * 24, 5), 1), (D.text(65536 * 8, 6), 4)):
-        stream = E.encode(data)
-        outs, status = run_batch(sim, [stream], [len(data)])
-        assert status == 0 and np.array_equal(outs[0], data)
-        assert sim.sim_last_policy() == want
+    sim.sim_set_order.argtypes = [ctypes.c_int]
+    try:
+        # (data, page schedule on?, expected threshold): in stream order the mixed pages differ from their
+        # neighbours; once the schedule has grouped them by size they do not
+        for data, order, want in ((D.mixed(65536 * 24, 5), 0, 1), (D.mixed(65536 * 24, 5), 1, 4), (D.text(65536 * 8, 6), 0, 4)):
+            sim.sim_set_order(order)
+            stream = E.encode(data)
+            outs, status = run_batch(sim, [stream], [len(data)])
+            assert status == 0 and np.array_equal(outs[0], data)
+            assert sim.sim_last_policy() == want
+    finally:
+        sim.sim_set_order(1)
 
 
 def test_sim_page_schedule_on_and_off(sim):
