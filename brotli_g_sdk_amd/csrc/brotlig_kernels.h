@@ -4,17 +4,20 @@
 // What it replaces: the reference's single D3D12 compute kernel CSMain
 // (src/decoder/BrotliGCompute.hlsl:1753-1882) and its CPU twin PageDecoder::Run
 // (src/decoder/PageDecoder.cpp:65-268).  Differences in design:
-//   * wave64 hosts TWO pages, one per 32-lane half (the format fixes 32 sub-streams per page);
+//   * wave64 hosts TWO pages at a time, one per 32-lane half (the format fixes 32 sub-streams per
+//     page), and each half takes its next page on its own (decode_pages);
 //   * symbols are decoded through LSB-first primary LUTs in LDS (one ds_read per symbol) with a
 //     canonical-code fallback for long codes, instead of the shader's <=16-step length search
 //     (BrotliGCompute.hlsl:500-526) or the CPU's three 64 KiB tables (BrotligHuffmanTable.cpp:44-71);
-//   * each lane streams its own sub-bitstream from global memory through a 64-bit window with a
-//     one-dword prefetch register;
+//   * each lane streams its own sub-bitstream from global memory through a 64-bit window, 64 queued
+//     bits and 64 bits in flight;
 //   * literals are routed straight to their output position (no literal FIFO);
-//   * the LZ77 copies of a round run lane-per-command in dependency levels: every copy whose
-//     source lies below the first unfinished command is independent and executes at once
-//     (the shader walks the 32 commands serially, BrotliGCompute.hlsl:1401-1419);
-//   * work is pulled from one device-side page counter by persistent waves.
+//   * the page is assembled in an LDS window; the LZ77 copies of a round run in dependency levels
+//     computed exactly (which earlier pieces own bytes of my source range), one lane per command
+//     or in teams of lanes for long copies (the shader walks the 32 commands serially,
+//     BrotliGCompute.hlsl:1401-1419);
+//   * work is pulled from one device-side counter by persistent waves, through a page schedule
+//     that puts similar pages side by side (order kernels below).
 //
 // Style rule: every wave::* call sits in wave-uniform control flow.  Per-lane loops and
 // branches contain only memory and ALU work.  (tests/sim runs this same source on the CPU with
