@@ -1047,12 +1047,9 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                 const bool last_group = g + 1u == ngroups;
                 const uint32_t J1 = last_group ? rlit : (F1 > prev_tail ? F1 - prev_tail : 0u);
                 const uint32_t keep_at = carry_head + prev_tail;        // ring index of consumption index `litcount` (mod 64)
-                for (; next_j < J1; next_j += 32u) {
-                    uint32_t ll;
-                    br.ensure(15);
-                    const uint32_t lit = decode_symbol<kLutBitsLit>(t_lit, br, ll);
-                    br.consume(ll);
-                    const uint32_t f = prev_tail + next_j;
+                // where literal number j of the round goes
+                auto place = [&](uint32_t j, uint32_t lit) {
+                    const uint32_t f = prev_tail + j;
                     if (f < litcount) {
                         uint32_t shift = shift1;
                         if (!one_run) {
@@ -1064,6 +1061,25 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                     } else {
                         L.carry[(keep_at + (f - litcount)) & 63u] = (uint8_t)lit;
                     }
+                };
+                // two literals per refill check while at least two are left (a literal is at most 15 bits)
+                for (; next_j + 32u < J1; next_j += 64u) {
+                    uint32_t l0, l1;
+                    br.ensure(30);
+                    const uint32_t lit0 = decode_symbol<kLutBitsLit>(t_lit, br, l0);
+                    br.consume(l0);
+                    const uint32_t lit1 = decode_symbol<kLutBitsLit>(t_lit, br, l1);
+                    br.consume(l1);
+                    place(next_j, lit0);
+                    place(next_j + 32u, lit1);
+                }
+                if (next_j < J1) {
+                    uint32_t ll;
+                    br.ensure(15);
+                    const uint32_t lit = decode_symbol<kLutBitsLit>(t_lit, br, ll);
+                    br.consume(ll);
+                    place(next_j, lit);
+                    next_j += 32u;
                 }
             }
             clk.lap(kPhLiterals);
