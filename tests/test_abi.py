@@ -36,6 +36,26 @@ def test_workspace_size_grows_with_streams():
     so.BrotligDecodeWorkspaceSize.restype = ctypes.c_size_t
     so.BrotligDecodeWorkspaceSize.argtypes = [ctypes.c_uint32]
     assert so.BrotligDecodeWorkspaceSize(4096) > so.BrotligDecodeWorkspaceSize(1) >= 1024
+    # with room for the page schedule: one word per 32 KiB page the output could hold, plus one per stream
+    so.BrotligDecodeWorkspaceSizeFor.restype = ctypes.c_size_t
+    so.BrotligDecodeWorkspaceSizeFor.argtypes = [ctypes.c_uint32, ctypes.c_uint64]
+    base = so.BrotligDecodeWorkspaceSize(16)
+    assert so.BrotligDecodeWorkspaceSizeFor(16, 0) >= base
+    assert so.BrotligDecodeWorkspaceSizeFor(16, 4 << 30) >= base + 4 * ((4 << 30) // 32768)
+
+
+def test_streamer_refuses_bad_arguments_without_a_device():
+    """Argument checks of the streaming front end come before any HIP call."""
+    so = ctypes.CDLL(_build.build_hip())
+    so.BrotligStreamerCreate.restype = ctypes.c_int
+    so.BrotligStreamerCreate.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p]
+    h = ctypes.c_void_p()
+    assert so.BrotligStreamerCreate(0, 1 << 20, 1 << 20, 16, ctypes.byref(h)) != 0          # no slots
+    assert so.BrotligStreamerCreate(3, 1 << 20, 1 << 20, 5000, ctypes.byref(h)) != 0       # > 4096 streams per batch
+    assert so.BrotligStreamerCreate(3, 1 << 20, 1 << 20, 16, None) != 0
+    so.BrotligStreamerWait.restype = ctypes.c_int
+    so.BrotligStreamerWait.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    assert so.BrotligStreamerWait(None, 1) != 0
 
 
 def test_product_does_not_reference_the_oracle():
