@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--pages-per-stream", type=int, default=4096)
     ap.add_argument("--distinct", type=int, default=256, help="distinct encoded pages per stream (tiled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="N > 1: also time an all-gather of the decoded shards (reported separately, never part of `value`)")
     args = ap.parse_args()
 
     import torch
@@ -183,6 +185,15 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item())
 
+    gather_ms = None
+    if args.gather and world > 1:                                       # optional exchange step, SURVEY.md 8(e)
+        barrier()
+        tg = time.perf_counter()
+        gathered, _ = shard.gather_outputs(dec.d_out[:dec.out_bytes])
+        barrier()
+        gather_ms = shard.max_over_ranks((time.perf_counter() - tg) * 1e3)
+        del gathered
+
     per_rank_u = dec.decompressed_bytes
     per_rank_c = dec.compressed_bytes
     ms_per_step = wall_ms / args.steps
@@ -228,6 +239,9 @@ def main():
                          "algorithmic_bytes_per_launch": per_rank_u + per_rank_c},
             "cpu_baseline": cpu,
         }
+        if gather_ms is not None:
+            line["gather"] = {"ms": round(gather_ms, 3), "what": "all-gather of the decoded shards over RCCL, outside `value`",
+                              "decode_plus_gather_GBps": round(total_u / ((ms_per_step + gather_ms) * 1e-3) / 1e9, 3)}
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist

@@ -29,3 +29,76 @@ def max_over_ranks(value):
 
 def sum_over_ranks(value):
     return int(_reduce(value, "SUM"))
+
+
+# ---- optional exchange steps around the decode ----------------------------------
+# Decoding needs no collective.  These two helpers cover the cases where the data does not start or
+# end sharded: compressed streams that arrive on one rank, and consumers that want the whole output
+# on every GPU.  Both are outside the timed region of bench.py unless --gather is given, and their
+# cost is reported separately (an all-gather of 32 GiB over xGMI costs about as much as the decode).
+
+def _device_for_backend():
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def scatter_streams(streams, src=0):
+    """`streams` (list of uint8 numpy arrays) is only meaningful on rank `src`; every rank returns the
+    slice of it that stream_indices() assigns to it.  Sizes travel first (broadcast), then one
+    point-to-point transfer per destination rank, grouped (ncclSend/ncclRecv under RCCL)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(streams)
+    world, rank, dev = dist.get_world_size(), dist.get_rank(), _device_for_backend()
+    n = torch.tensor([len(streams) if rank == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src)
+    sizes = torch.zeros(int(n.item()), dtype=torch.int64, device=dev)
+    if rank == src:
+        sizes.copy_(torch.tensor([len(s) for s in streams], dtype=torch.int64))
+    dist.broadcast(sizes, src)
+    sizes = sizes.cpu().tolist()
+    mine = stream_indices(len(sizes), world, rank)
+    if rank == src:
+        ops, keep = [], []
+        for r in range(world):
+            idx = stream_indices(len(sizes), world, r)
+            if r == src or not idx:
+                continue
+            buf = torch.from_numpy(np.concatenate([np.asarray(streams[i], dtype=np.uint8) for i in idx])).to(dev)
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, r))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return [np.asarray(streams[i], dtype=np.uint8) for i in mine]
+    total = sum(sizes[i] for i in mine)
+    if total == 0:
+        return []
+    buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, src)]):
+        w.wait()
+    host, out, pos = buf.cpu().numpy(), [], 0
+    for i in mine:
+        out.append(host[pos:pos + sizes[i]].copy())
+        pos += sizes[i]
+    return out
+
+
+def gather_outputs(local):
+    """All-gather of each rank's decoded bytes (a 1-D uint8 tensor on the backend's device; lengths may
+    differ).  Returns (gathered [world, padded_len] tensor, list of true lengths)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local.reshape(1, -1), [local.numel()]
+    world = dist.get_world_size()
+    lens = torch.zeros(world, dtype=torch.int64, device=local.device)
+    lens[dist.get_rank()] = local.numel()
+    dist.all_reduce(lens, op=dist.ReduceOp.SUM)
+    padded = int(lens.max().item())
+    send = local if local.numel() == padded else torch.cat([local, local.new_zeros(padded - local.numel())])
+    out = torch.empty(world * padded, dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out, send.contiguous())
+    return out.reshape(world, padded), lens.cpu().tolist()
