@@ -145,8 +145,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device(dev))
-    from brotli_g_sdk_amd import api
+    from brotli_g_sdk_amd import api, _build
 
+    # the in-tree libraries are normally prebuilt; should one be stale, only one rank per node rebuilds it
+    if local_rank == 0:
+        _build.build_encoder()
+        api.lib()
+    if world > 1:
+        dist.barrier()
     api.DeviceSelfTest()
     distinct = min(args.distinct, args.pages_per_stream)
     from brotli_g_sdk_amd import shard
