@@ -13,6 +13,7 @@
 // It is NOT part of the decode product path.
 #include <algorithm>
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -408,8 +409,30 @@ std::vector<uint8_t> encode_page(const uint8_t* data, uint32_t n, const BrotligE
     if (o.flags & BROTLIG_ENC_FORCE_STORED) return out;
     std::vector<Command> cmds; std::vector<uint8_t> lits;
     parse_page(data, n, o, cmds, lits);
-    const uint32_t npostfix = o.npostfix & 3, ndirect = (o.ndirect_m & 15) << npostfix;
-    assign_symbols(cmds, npostfix, ndirect, !(o.flags & BROTLIG_ENC_NO_RING_CODES));
+    uint32_t npostfix = o.npostfix & 3, ndirect = (o.ndirect_m & 15) << npostfix;
+    const bool use_ring = !(o.flags & BROTLIG_ENC_NO_RING_CODES);
+    if (o.flags & BROTLIG_ENC_SEARCH_DIST_PARAMS) {
+        // NPOSTFIX / NDIRECT search (the reference does one per page too, PageEncoder.cpp:324-377): the
+        // parse is fixed, so every candidate is priced by the entropy of its distance symbols plus
+        // their extra bits, and the cheapest pair is kept.
+        double best = 1e300;
+        uint32_t best_np = npostfix, best_nd = ndirect;
+        for (uint32_t np = 0; np < 4; ++np) {
+            for (uint32_t m : {0u, 1u, 2u, 4u, 8u, 12u, 15u}) {
+                std::vector<Command> trial = cmds;
+                assign_symbols(trial, np, m << np, use_ring);
+                std::vector<uint32_t> hd(kDistAlphabet, 0);
+                double bits = 0; uint32_t total = 0;
+                for (auto& c : trial) if (c.has_dist_sym) { ++hd[c.dist_sym]; ++total; bits += c.dist_nbits; }
+                for (uint32_t cnt : hd) if (cnt) bits += cnt * std::log2((double)total / cnt);
+                uint32_t used = 0; for (uint32_t cnt : hd) used += cnt != 0;
+                bits += 5.0 * used;                                    // rough price of describing the code
+                if (bits < best) { best = bits; best_np = np; best_nd = m << np; }
+            }
+        }
+        npostfix = best_np; ndirect = best_nd;
+    }
+    assign_symbols(cmds, npostfix, ndirect, use_ring);
 
     std::vector<uint32_t> hicp(kIcpAlphabet, 0), hdist(kDistAlphabet, 0), hlit(kLitAlphabet, 0);
     for (auto& c : cmds) { ++hicp[c.icp_sym]; if (c.has_dist_sym) ++hdist[c.dist_sym]; }

@@ -24,7 +24,8 @@ enum {
     BROTLIG_ENC_NO_RING_CODES       = 1u << 2,  /* never use distance codes 0..15 */
     BROTLIG_ENC_NO_LAZY             = 1u << 3,  /* greedy parse */
     BROTLIG_ENC_LITERALS_ONLY       = 1u << 4,  /* no matches: one insert-only command */
-    BROTLIG_ENC_FORCE_COMPLEX_TABLES= 1u << 5   /* complex description even for 2..4 symbols */
+    BROTLIG_ENC_FORCE_COMPLEX_TABLES= 1u << 5,  /* complex description even for 2..4 symbols */
+    BROTLIG_ENC_SEARCH_DIST_PARAMS  = 1u << 6   /* per page: pick NPOSTFIX / NDIRECT by estimated distance cost */
 };
 
 typedef struct BrotligEncodeOptions {

@@ -122,6 +122,7 @@ int compress(const Options& o, const std::vector<uint8_t>& src)
 {
     BrotligEncodeOptions e{};
     e.page_size = o.page_size;
+    e.flags = BROTLIG_ENC_SEARCH_DIST_PARAMS;                          // per-page NPOSTFIX / NDIRECT search
     if (o.precondition) {
         if (o.format < 1 || o.format > 5 || !o.tex_width || !o.tex_height) {
             fprintf(stderr, "brotlig: -precondition needs -data-format 1..5, -texture-width and -texture-height\n");
