@@ -50,6 +50,10 @@ def build_bc3_streams(indices, distinct):
     return streams, expected
 
 
+ENCODER_FLAGS = 0        # brotli_g_sdk_amd.encoder flags for the synthetic streams (--encoder-flags)
+PREENCODED = None      # optional {stream index: encoded `distinct`-page stream}, see --preencoded
+
+
 def build_streams(kind, indices, pages_per_stream, distinct):
     """Builds the streams with the given global indices (the seed of a stream is its index).
     Returns (streams, expected_distinct) where expected_distinct[k] is the decompressed bytes of
@@ -77,7 +81,7 @@ def build_streams(kind, indices, pages_per_stream, distinct):
             data = D.samples16(distinct * PAGE, seed)
         else:
             raise SystemExit(f"unknown workload {kind}")
-        small = E.encode(data)
+        small = PREENCODED[seed] if PREENCODED is not None and seed in PREENCODED else E.encode(data, flags=ENCODER_FLAGS)
         rep = pages_per_stream // distinct
         streams.append(D.tile_stream(small, rep) if rep > 1 else small)
         expected.append(data)
@@ -130,10 +134,19 @@ def main():
     ap.add_argument("--pages-per-stream", type=int, default=4096)
     ap.add_argument("--distinct", type=int, default=256, help="distinct encoded pages per stream (tiled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--encoder-flags", type=int, default=0,
+                    help="encoder flags for the synthetic streams (192 = optimal parse + distance parameter search; slow)")
+    ap.add_argument("--preencoded", default=None,
+                    help=".npz of streams made by profiles/tools/preencode.py with the same workload / distinct / flags")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also time an all-gather of the decoded shards (reported separately, never part of `value`)")
     args = ap.parse_args()
 
+    global ENCODER_FLAGS, PREENCODED
+    ENCODER_FLAGS = args.encoder_flags
+    if args.preencoded:
+        z = np.load(args.preencoded)
+        PREENCODED = {int(k): z[k] for k in z.files}
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -233,7 +246,7 @@ def main():
             "config": {"workload": (f"{args.streams} streams x {args.pages_per_stream} pages x 64 KiB per GPU "
                                     f"({per_rank_u / 2**30:.2f} GiB), '{args.workload}' synthetic "
                                     f"(BASELINE.json configs[2] when mixed), {distinct} distinct encoded pages per stream "
-                                    f"tiled, compression ratio {per_rank_u / per_rank_c:.2f}") if args.workload != "bc3" else
+                                    f"tiled, compression ratio {per_rank_u / per_rank_c:.2f}" + (f", encoder flags {args.encoder_flags}" if args.encoder_flags or args.preencoded else "")) if args.workload != "bc3" else
                                    (f"{args.streams} BC3 textures of {BC3_BLOCKS}x{BC3_BLOCKS} blocks (16 MiB, 256 pages each, "
                                     f"{per_rank_u / 2**30:.2f} GiB per GPU), swizzle + delta pre-conditioning, "
                                     f"{max(1, min(distinct, 8))} distinct textures repeated (BASELINE.json configs[3]; BC7 is not a "

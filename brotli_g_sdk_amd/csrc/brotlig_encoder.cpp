@@ -334,6 +334,39 @@ void parse_page(const uint8_t* data, uint32_t n, const BrotligEncodeOptions& o, 
     }
 }
 
+// Distance code of `dist` given the ring and the page's NPOSTFIX / NDIRECT (PageDecoder.cpp:345-404).
+inline int distance_code(uint32_t dist, const uint32_t ring[4], uint32_t npostfix, uint32_t ndirect, bool use_ring,
+                         uint32_t& nbits, uint32_t& extra)
+{
+    nbits = 0; extra = 0;
+    if (use_ring) {
+        if (dist == ring[0]) return 0;
+        if (dist == ring[1]) return 1;
+        if (dist == ring[2]) return 2;
+        if (dist == ring[3]) return 3;
+        static const int add[6] = {-1, 1, -2, 2, -3, 3};
+        for (int k = 0; k < 6; ++k) if ((int64_t)ring[0] + add[k] > 0 && (uint32_t)((int64_t)ring[0] + add[k]) == dist) return 4 + k;
+        for (int k = 0; k < 6; ++k) if ((int64_t)ring[1] + add[k] > 0 && (uint32_t)((int64_t)ring[1] + add[k]) == dist) return 10 + k;
+    }
+    if (dist <= ndirect) return (int)(15 + dist);
+    const uint32_t x = dist - ndirect - 1;
+    const uint32_t l = x & ((1u << npostfix) - 1);
+    const uint32_t y = (x >> npostfix) + 4;
+    nbits = bit_width(y) - 2;
+    const uint32_t p = (y >> nbits) & 1;
+    const uint32_t h = 2 * (nbits - 1) + p;
+    extra = y - ((2 + p) << nbits);
+    return (int)(16 + ndirect + ((h << npostfix) | l));
+}
+// Insert-and-copy symbol of (insert code, copy code); `implicit` = distance code 0 folded into the symbol.
+inline uint16_t icp_symbol(uint32_t ic, uint32_t cc, bool implicit)
+{
+    const uint32_t b = (cc & 7) | ((ic & 7) << 3);
+    if (implicit) return (uint16_t)(b | (cc >= 8 ? 64 : 0));
+    const uint32_t off = 2 * ((cc >> 3) + 3 * (ic >> 3));
+    return (uint16_t)(((off << 5) + 0x40 + ((0x520D40u >> off) & 0xC0)) | b);
+}
+
 // distance -> (symbol, extra) with the decoder's ring semantics (PageDecoder.cpp:345-404)
 void assign_symbols(std::vector<Command>& cmds, uint32_t npostfix, uint32_t ndirect, bool use_ring)
 {
@@ -348,45 +381,148 @@ void assign_symbols(std::vector<Command>& cmds, uint32_t npostfix, uint32_t ndir
             continue;
         }
         uint32_t cc = code_of(kCopyBase, c.copy_len);
-        // distance code
-        int code = -1;
-        if (use_ring) {
-            if (c.dist == ring[0]) code = 0;
-            else if (c.dist == ring[1]) code = 1;
-            else if (c.dist == ring[2]) code = 2;
-            else if (c.dist == ring[3]) code = 3;
-            else {
-                static const int add[6] = {-1, 1, -2, 2, -3, 3};
-                for (int k = 0; k < 6 && code < 0; ++k) if ((int64_t)ring[0] + add[k] > 0 && (uint32_t)((int64_t)ring[0] + add[k]) == c.dist) code = 4 + k;
-                for (int k = 0; k < 6 && code < 0; ++k) if ((int64_t)ring[1] + add[k] > 0 && (uint32_t)((int64_t)ring[1] + add[k]) == c.dist) code = 10 + k;
-            }
-        }
-        if (code < 0) {
-            if (c.dist <= ndirect) code = (int)(15 + c.dist);
-            else {
-                uint32_t x = c.dist - ndirect - 1;
-                uint32_t l = x & ((1u << npostfix) - 1);
-                uint32_t y = (x >> npostfix) + 4;
-                uint32_t nbits = bit_width(y) - 2;
-                uint32_t p = (y >> nbits) & 1;
-                uint32_t h = 2 * (nbits - 1) + p;
-                c.dist_extra = y - ((2 + p) << nbits);
-                c.dist_nbits = nbits;
-                code = (int)(16 + ndirect + ((h << npostfix) | l));
-            }
-        }
+        const int code = distance_code(c.dist, ring, npostfix, ndirect, use_ring, c.dist_nbits, c.dist_extra);
         const bool implicit = code == 0 && ic < 8 && cc < 16;
-        uint32_t b = (cc & 7) | ((ic & 7) << 3);
-        if (implicit) c.icp_sym = (uint16_t)(b | (cc >= 8 ? 64 : 0));
-        else {
-            uint32_t off = 2 * ((cc >> 3) + 3 * (ic >> 3));
-            c.icp_sym = (uint16_t)(((off << 5) + 0x40 + ((0x520D40u >> off) & 0xC0)) | b);
-            c.has_dist_sym = true; c.dist_sym = (uint16_t)code;
-        }
+        c.icp_sym = icp_symbol(ic, cc, implicit);
+        if (!implicit) { c.has_dist_sym = true; c.dist_sym = (uint16_t)code; }
         c.extra_nbits = kInsExtra[ic] + kCopyExtra[cc];
         // insert extra in the low bits, copy extra above; both fields <= 24 bits so emit separately
         c.extra_bits_val = 0;   // emitted field-wise in emit_command
         if (code != 0) { ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = c.dist; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Optimal parse (opt-in, BROTLIG_ENC_OPTIMAL_PARSE): shortest path over the page's positions under a
+// bit-cost model taken from a previous parse of the same page -- the idea of the reference's
+// Zopfli-style pass (src/encoder/PageEncoder.cpp:87-147 drives brotli's backward-references code),
+// restated here in a simple form: a node is a command boundary, an edge is one command
+// (insert run + copy), priced as -log2 of the symbol frequencies plus extra bits.
+struct CostModel {
+    float lit[256], icp[kIcpAlphabet], dist[kDistAlphabet];
+    void from_histograms(const std::vector<uint32_t>& hl, const std::vector<uint32_t>& hi, const std::vector<uint32_t>& hd)
+    {
+        auto fill = [](const std::vector<uint32_t>& h, float* out, size_t n) {
+            double total = 0; for (size_t k = 0; k < n; ++k) total += h[k];
+            const double missing = std::log2(total + 2.0) + 1.0;        // a symbol the previous parse never used
+            // a prefix code spends at least one bit per symbol, however frequent
+            for (size_t k = 0; k < n; ++k) out[k] = h[k] ? std::max(1.0f, (float)std::log2(total / h[k])) : (float)missing;
+        };
+        fill(hl, lit, 256); fill(hi, icp, kIcpAlphabet); fill(hd, dist, kDistAlphabet);
+    }
+};
+
+struct PathNode {
+    float cost;                 // cheapest way to have a command boundary here
+    uint32_t from, ins, len, dist;
+    uint32_t ring[4];           // distance ring after the command that ends here
+};
+
+void parse_page_optimal(const uint8_t* data, uint32_t n, const BrotligEncodeOptions& o, uint32_t npostfix, uint32_t ndirect,
+                        const CostModel& cm, std::vector<Command>& cmds, std::vector<uint8_t>& literals)
+{
+    const bool use_ring = !(o.flags & BROTLIG_ENC_NO_RING_CODES);
+    const uint32_t max_chain = o.max_chain ? o.max_chain : 24;
+    Parser P; P.d = data; P.n = n; P.max_chain = max_chain; P.lazy = false; P.use_ring = use_ring;
+    P.head.assign(1u << Parser::kHashBits, -1); P.prev.assign(n, -1);
+    std::vector<float> litcum(n + 1, 0.f);
+    for (uint32_t i = 0; i < n; ++i) litcum[i + 1] = litcum[i] + cm.lit[data[i]];
+    const float kInf = 1e30f;
+    std::vector<PathNode> node(n + 1);
+    for (auto& nd : node) { nd.cost = kInf; nd.from = 0; nd.ins = nd.len = nd.dist = 0; }
+    node[0].cost = 0; node[0].ring[0] = 4; node[0].ring[1] = 11; node[0].ring[2] = 15; node[0].ring[3] = 16;
+    // the few cheapest boundaries to start the next command from: key = cost - literal cost up to there
+    constexpr int kStarts = 4;
+    uint32_t starts[kStarts]; int nstarts = 0;
+    auto key = [&](uint32_t i) { return node[i].cost - litcum[i]; };
+    auto push_start = [&](uint32_t i) {                                 // `starts` stays sorted by key, cheapest first
+        int k;
+        if (nstarts < kStarts) k = nstarts++;
+        else if (key(i) < key(starts[kStarts - 1])) k = kStarts - 1;
+        else return;
+        starts[k] = i;
+        while (k > 0 && key(starts[k - 1]) > key(starts[k])) { std::swap(starts[k - 1], starts[k]); --k; }
+    };
+    auto relax = [&](uint32_t i, uint32_t p, uint32_t len, uint32_t dist) {
+        const PathNode& a = node[i];
+        const uint32_t ins = p - i;
+        const uint32_t ic = code_of(kInsBase, ins), cc = code_of(kCopyBase, len);
+        uint32_t nb, ex;
+        const int code = distance_code(dist, a.ring, npostfix, ndirect, use_ring, nb, ex);
+        const bool implicit = code == 0 && ic < 8 && cc < 16;
+        float c = a.cost + (litcum[p] - litcum[i]) + cm.icp[icp_symbol(ic, cc, implicit)] + (float)(kInsExtra[ic] + kCopyExtra[cc]);
+        if (!implicit) c += cm.dist[code] + (float)nb;
+        PathNode& b = node[p + len];
+        if (c < b.cost) {
+            b.cost = c; b.from = i; b.ins = ins; b.len = len; b.dist = dist;
+            if (code != 0) { b.ring[0] = dist; b.ring[1] = a.ring[0]; b.ring[2] = a.ring[1]; b.ring[3] = a.ring[2]; }
+            else { b.ring[0] = a.ring[0]; b.ring[1] = a.ring[1]; b.ring[2] = a.ring[2]; b.ring[3] = a.ring[3]; }
+        }
+    };
+    for (uint32_t p = 0; p < n; ++p) {
+        if (node[p].cost < kInf) push_start(p);
+        if (nstarts == 0) { P.insert(p); continue; }
+        const uint32_t maxlen = n - p;
+        // candidate matches at p: ring distances of the best start, then the hash chain (nearest first,
+        // only strictly longer ones are kept)
+        struct M { uint32_t len, dist; } cand[48]; int nc = 0;
+        if (use_ring) {
+            const uint32_t* r = node[starts[0]].ring;
+            for (int k = 0; k < 4; ++k) {
+                if (r[k] == 0 || r[k] > p) continue;
+                const uint32_t l = P.match_len(p - r[k], p, maxlen);
+                if (l >= 2 && nc < 48) cand[nc++] = {l, r[k]};
+            }
+        }
+        uint32_t best_chain = 3;
+        if (p + 4 <= n) {
+            int32_t c = P.head[P.hash4(p)];
+            for (uint32_t it = 0; c >= 0 && it < max_chain && nc < 48; ++it, c = P.prev[c]) {
+                const uint32_t l = P.match_len((uint32_t)c, p, maxlen);
+                if (l > best_chain) { best_chain = l; cand[nc++] = {l, p - (uint32_t)c}; if (l == maxlen) break; }
+            }
+        }
+        uint32_t longest = 0;
+        for (int m = 0; m < nc; ++m) {
+            const uint32_t L = cand[m].len, dist = cand[m].dist;
+            longest = std::max(longest, L);
+            for (int si = 0; si < nstarts; ++si) {
+                const uint32_t i = starts[si];
+                if (L >= 96) { relax(i, p, L, dist); continue; }           // long match: whole length only
+                for (uint32_t l = (dist == node[i].ring[0] ? 2u : std::min(L, 4u)); l <= L; ++l) relax(i, p, l, dist);
+            }
+        }
+        P.insert(p);
+        if (longest >= 128) {                                              // skip through long matches (runs)
+            const uint32_t end = p + longest;
+            for (uint32_t q = p + 1; q < end && q < n; ++q) { if (node[q].cost < kInf) push_start(q); P.insert(q); }
+            p = end - 1;
+        }
+    }
+    // the tail: literals after the last command boundary go into an insert-only command
+    uint32_t best_i = 0; float best = kInf;
+    for (uint32_t i = 0; i <= n; ++i) {
+        if (node[i].cost >= kInf) continue;
+        float c = node[i].cost + (litcum[n] - litcum[i]);
+        if (i < n) { const uint32_t ic = code_of(kInsBase, n - i); c += cm.icp[704 + ic] + (float)kInsExtra[ic]; }
+        if (c < best) { best = c; best_i = i; }
+    }
+    std::vector<Command> rev;
+    for (uint32_t i = best_i; i != 0; i = node[i].from) {
+        Command c{}; c.insert_len = node[i].ins; c.copy_len = node[i].len; c.dist = node[i].dist;
+        rev.push_back(c);
+    }
+    cmds.assign(rev.rbegin(), rev.rend());
+    literals.clear();
+    uint32_t pos = 0;
+    for (auto& c : cmds) {
+        literals.insert(literals.end(), data + pos, data + pos + c.insert_len);
+        pos += c.insert_len + c.copy_len;
+    }
+    if (pos < n) {
+        Command c{}; c.insert_len = n - pos; c.copy_len = 0; c.dist = 0;
+        literals.insert(literals.end(), data + pos, data + n);
+        cmds.push_back(c);
     }
 }
 
@@ -403,7 +539,7 @@ void emit_command(BitWriter& w, const Command& c, const PrefixCode& icp, const P
 }
 
 // Returns the compressed page (empty = store raw).
-std::vector<uint8_t> encode_page(const uint8_t* data, uint32_t n, const BrotligEncodeOptions& o, bool is_delta)
+std::vector<uint8_t> encode_page_once(const uint8_t* data, uint32_t n, const BrotligEncodeOptions& o, bool is_delta)
 {
     std::vector<uint8_t> out;
     if (o.flags & BROTLIG_ENC_FORCE_STORED) return out;
@@ -435,9 +571,23 @@ std::vector<uint8_t> encode_page(const uint8_t* data, uint32_t n, const BrotligE
     assign_symbols(cmds, npostfix, ndirect, use_ring);
 
     std::vector<uint32_t> hicp(kIcpAlphabet, 0), hdist(kDistAlphabet, 0), hlit(kLitAlphabet, 0);
-    for (auto& c : cmds) { ++hicp[c.icp_sym]; if (c.has_dist_sym) ++hdist[c.dist_sym]; }
-    ++hicp[704];
-    for (uint8_t b : lits) ++hlit[b];
+    auto histograms = [&]() {
+        std::fill(hicp.begin(), hicp.end(), 0u); std::fill(hdist.begin(), hdist.end(), 0u); std::fill(hlit.begin(), hlit.end(), 0u);
+        for (auto& c : cmds) { ++hicp[c.icp_sym]; if (c.has_dist_sym) ++hdist[c.dist_sym]; }
+        ++hicp[704];
+        for (uint8_t b : lits) ++hlit[b];
+    };
+    histograms();
+    if ((o.flags & BROTLIG_ENC_OPTIMAL_PARSE) && !(o.flags & BROTLIG_ENC_LITERALS_ONLY) && n >= 16) {
+        // two rounds: each re-parses under the symbol costs of the previous parse
+        for (int round = 0; round < 2; ++round) {
+            CostModel cm;
+            cm.from_histograms(hlit, hicp, hdist);
+            parse_page_optimal(data, n, o, npostfix, ndirect, cm, cmds, lits);
+            assign_symbols(cmds, npostfix, ndirect, use_ring);
+            histograms();
+        }
+    }
     uint32_t pad_lit = 0;
     for (uint32_t s = 1; s < 256; ++s) if (hlit[s] > hlit[pad_lit]) pad_lit = s;   // PageEncoder.cpp:518-537
 
@@ -502,6 +652,19 @@ std::vector<uint8_t> encode_page(const uint8_t* data, uint32_t n, const BrotligE
     for (uint32_t i = 0; i < kNumStreams; ++i) out.insert(out.end(), S.w[i].bytes.begin(), S.w[i].bytes.end());
     out.resize(Ssz, 0);
     return out;
+}
+
+// With the optimal parse asked for, the page is encoded both ways and the smaller result kept: the
+// cost model prices symbols, not the description of the prefix codes, and on very compressible pages
+// (a few hundred bytes) a parse that uses more distinct symbols can lose more there than it gains.
+std::vector<uint8_t> encode_page(const uint8_t* data, uint32_t n, const BrotligEncodeOptions& o, bool is_delta)
+{
+    if (!(o.flags & BROTLIG_ENC_OPTIMAL_PARSE)) return encode_page_once(data, n, o, is_delta);
+    BrotligEncodeOptions lazy = o;
+    lazy.flags &= ~(uint32_t)BROTLIG_ENC_OPTIMAL_PARSE;
+    std::vector<uint8_t> a = encode_page_once(data, n, lazy, is_delta), b = encode_page_once(data, n, o, is_delta);
+    const size_t sa = a.empty() ? n : a.size(), sb = b.empty() ? n : b.size();   // empty = stored raw
+    return sb < sa ? b : a;
 }
 
 // ---------------------------------------------------------------------------------------

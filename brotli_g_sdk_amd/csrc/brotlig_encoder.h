@@ -25,7 +25,8 @@ enum {
     BROTLIG_ENC_NO_LAZY             = 1u << 3,  /* greedy parse */
     BROTLIG_ENC_LITERALS_ONLY       = 1u << 4,  /* no matches: one insert-only command */
     BROTLIG_ENC_FORCE_COMPLEX_TABLES= 1u << 5,  /* complex description even for 2..4 symbols */
-    BROTLIG_ENC_SEARCH_DIST_PARAMS  = 1u << 6   /* per page: pick NPOSTFIX / NDIRECT by estimated distance cost */
+    BROTLIG_ENC_SEARCH_DIST_PARAMS  = 1u << 6,  /* per page: pick NPOSTFIX / NDIRECT by estimated distance cost */
+    BROTLIG_ENC_OPTIMAL_PARSE       = 1u << 7   /* shortest-path parse under the symbol costs of a first (lazy) parse */
 };
 
 typedef struct BrotligEncodeOptions {

@@ -13,6 +13,7 @@ NO_LAZY = 1 << 3
 LITERALS_ONLY = 1 << 4
 FORCE_COMPLEX_TABLES = 1 << 5
 SEARCH_DIST_PARAMS = 1 << 6      # per page: NPOSTFIX / NDIRECT chosen by estimated distance cost
+OPTIMAL_PARSE = 1 << 7           # shortest-path parse under the symbol costs of a first (lazy) parse
 
 FORMAT_BC1, FORMAT_BC2, FORMAT_BC3, FORMAT_BC4, FORMAT_BC5 = 1, 2, 3, 4, 5
 

@@ -29,7 +29,7 @@ struct Options {
     bool precondition = false, swizzle = false, delta = false, pitch_aligned = false;
     uint32_t format = 0, tex_width = 0, tex_height = 0, row_pitch = 0, num_mips = 1;
     uint32_t repeat = 1;
-    bool verbose = false;
+    bool verbose = false, fast = false;
     std::string src, dst;
 };
 
@@ -52,6 +52,7 @@ void usage()
            " -gpu                          : decompress on the GPU (always the case here)\n"
            " -warp                         : ignored\n"
            " -num-repeat <value>           : repeat the task (default 1)\n"
+           " -fast                         : quicker compression (lazy parse, default distance parameters)\n"
            " -verbose                      : print progress\n");
 }
 
@@ -102,6 +103,7 @@ bool parse(int argc, char** argv, Options& o)
         else if (!strcmp(a, "-gpu") || !strcmp(a, "-warp")) {}
         else if (!strcmp(a, "-num-repeat")) { if (!value(i, o.repeat)) return false; }
         else if (!strcmp(a, "-verbose")) o.verbose = true;
+        else if (!strcmp(a, "-fast")) o.fast = true;
         else if (!strcmp(a, "-brotli")) { fprintf(stderr, "brotlig: the stock-Brotli mode of the sample is not provided\n"); return false; }
         else if (!strcmp(a, "-brotli-quality") || !strcmp(a, "-brotli-windowsize") || !strcmp(a, "-brotli-decode-output-size")) { value(i, ignored); }
         else if (a[0] == '-') { fprintf(stderr, "brotlig: unknown option %s\n", a); return false; }
@@ -122,7 +124,8 @@ int compress(const Options& o, const std::vector<uint8_t>& src)
 {
     BrotligEncodeOptions e{};
     e.page_size = o.page_size;
-    e.flags = BROTLIG_ENC_SEARCH_DIST_PARAMS;                          // per-page NPOSTFIX / NDIRECT search
+    // best ratio by default: shortest-path parse and per-page NPOSTFIX / NDIRECT search; -fast keeps the lazy parse
+    e.flags = o.fast ? 0u : (BROTLIG_ENC_SEARCH_DIST_PARAMS | BROTLIG_ENC_OPTIMAL_PARSE);
     if (o.precondition) {
         if (o.format < 1 || o.format > 5 || !o.tex_width || !o.tex_height) {
             fprintf(stderr, "brotlig: -precondition needs -data-format 1..5, -texture-width and -texture-height\n");
