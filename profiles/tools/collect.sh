@@ -13,7 +13,7 @@ python bench.py > "$out/bench.json" 2> "$out/bench.err"
 python bench.py --workload bc3 --streams 256 --no-cpu-baseline > "$out/bench_bc3.json" 2>> "$out/bench.err"
 python bench.py --workload runs --streams 1 --no-cpu-baseline > "$out/bench_runs.json" 2>> "$out/bench.err"
 python bench.py --workload text --no-cpu-baseline > "$out/bench_text.json" 2>> "$out/bench.err"
-for k in mixed text runs bc3; do python profiles/phase_profile.py $k; done > "$out/phase_profile.jsonl" 2>> "$out/bench.err"
+for k in "mixed 16" "text 16" "runs 16" "bc3 64"; do python profiles/phase_profile.py $k; done > "$out/phase_profile.jsonl" 2>> "$out/bench.err"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o f -- python "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$out/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o f -- python "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1
