@@ -26,7 +26,7 @@ def _hipcc():
 def build_encoder(force=False):
     src = [os.path.join(CSRC, "brotlig_encoder.cpp"), os.path.join(CSRC, "brotlig_encoder.h")]
     if force or _stale(ENC_SO, src):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ENC_SO, src[0]], cwd=CSRC)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", ENC_SO, src[0]], cwd=CSRC)
     return ENC_SO
 
 
@@ -55,7 +55,7 @@ def build_cli(force=False):
     src = os.path.join(ROOT, "tools", "brotlig_cli.cpp")
     if force or _stale(CLI_BIN, [src, ENC_SO, HIP_SO]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", CLI_BIN, src,
-                               "-L", CSRC, "-lbrotlig_enc", "-lbrotlig_hip", "-Wl,-rpath,$ORIGIN/../brotli_g_sdk_amd/csrc"])
+                               "-L", CSRC, "-lbrotlig_enc", "-lbrotlig_hip", "-pthread", "-Wl,-rpath,$ORIGIN/../brotli_g_sdk_amd/csrc"])
     return CLI_BIN
 
 

@@ -12,6 +12,8 @@
 //   conditioning   : src/common/BrotligDataConditioner.cpp:28-119, PageEncoder.cpp:576-612
 // It is NOT part of the decode product path.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdint>
 #include <cmath>
 #include <cstring>
@@ -790,19 +792,33 @@ extern "C" int BrotligEncode(uint32_t input_size, const uint8_t* src, uint32_t* 
         data = cond.data();
     }
 
+    // pages are independent: workers pull page indices from one counter (the reference fans its
+    // PageEncoderJob out the same way, src/BrotligEncoder.cpp:380-413); the result does not depend on
+    // the number of workers
     std::vector<std::vector<uint8_t>> pages(num_pages);
-    std::vector<uint8_t> work(page_size);
-    for (uint64_t i = 0; i < num_pages; ++i) {
-        const uint32_t off = (uint32_t)(i * page_size), n = std::min<uint32_t>(page_size, input_size - off);
-        const uint8_t* pg = data + off;
-        bool is_delta = false;
-        if (o.precondition && o.delta) {
-            memcpy(work.data(), pg, n);
-            delta_encode_page(dc, off, (size_t)off + n, work.data());
-            pg = work.data(); is_delta = true;
+    std::atomic<uint64_t> next{0};
+    auto worker = [&]() {
+        std::vector<uint8_t> work(page_size);
+        for (uint64_t i = next.fetch_add(1); i < num_pages; i = next.fetch_add(1)) {
+            const uint32_t off = (uint32_t)(i * page_size), n = std::min<uint32_t>(page_size, input_size - off);
+            const uint8_t* pg = data + off;
+            bool is_delta = false;
+            if (o.precondition && o.delta) {
+                memcpy(work.data(), pg, n);
+                delta_encode_page(dc, off, (size_t)off + n, work.data());
+                pg = work.data(); is_delta = true;
+            }
+            pages[i] = encode_page(pg, n, o, is_delta);
+            if (pages[i].empty()) pages[i].assign(data + off, data + off + n);   // stored: conditioned, not delta (PageEncoder.cpp:321)
         }
-        pages[i] = encode_page(pg, n, o, is_delta);
-        if (pages[i].empty()) pages[i].assign(data + off, data + off + n);   // stored: conditioned, not delta (PageEncoder.cpp:321)
+    };
+    uint32_t nthreads = o.num_threads ? o.num_threads : std::max(1u, std::thread::hardware_concurrency());
+    nthreads = (uint32_t)std::min<uint64_t>(std::min(nthreads, 64u), num_pages);
+    if (nthreads <= 1) worker();
+    else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+        for (auto& t : pool) t.join();
     }
 
     uint64_t need = 8 + (o.precondition ? 8 : 0) + 4 * num_pages;

@@ -38,6 +38,7 @@ typedef struct BrotligEncodeOptions {
     /* pre-conditioning (BC1..BC5 block textures) */
     uint32_t precondition, swizzle, delta, format;
     uint32_t width_blocks, height_blocks, num_mips, pitch_bytes, pitch_d3d12_aligned;
+    uint32_t num_threads;    /* page-parallel workers; 0 -> one per hardware thread, at most 64 */
 } BrotligEncodeOptions;
 
 uint32_t BrotligEncMaxCompressedSize(uint32_t input_size, uint32_t page_size);

@@ -22,7 +22,7 @@ class _Options(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in (
         "page_size", "npostfix", "ndirect_m", "flags", "max_chain",
         "precondition", "swizzle", "delta", "format",
-        "width_blocks", "height_blocks", "num_mips", "pitch_bytes", "pitch_d3d12_aligned")]
+        "width_blocks", "height_blocks", "num_mips", "pitch_bytes", "pitch_d3d12_aligned", "num_threads")]
 
 
 _lib = None
@@ -40,7 +40,7 @@ def _load():
     return _lib
 
 
-def encode(data, page_size=65536, npostfix=0, ndirect_m=0, flags=0, max_chain=0, precondition=None) -> np.ndarray:
+def encode(data, page_size=65536, npostfix=0, ndirect_m=0, flags=0, max_chain=0, precondition=None, threads=0) -> np.ndarray:
     """Encode `data` (bytes-like / uint8 array) into one .brotlig stream (uint8 array).
 
     precondition: None, or a dict(format=1..5, width_blocks, height_blocks, num_mips=1, swizzle=False,
@@ -49,7 +49,8 @@ def encode(data, page_size=65536, npostfix=0, ndirect_m=0, flags=0, max_chain=0,
     lib = _load()
     src = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data,
                                dtype=np.uint8)
-    o = _Options(page_size=page_size, npostfix=npostfix, ndirect_m=ndirect_m, flags=flags, max_chain=max_chain)
+    o = _Options(page_size=page_size, npostfix=npostfix, ndirect_m=ndirect_m, flags=flags, max_chain=max_chain,
+                 num_threads=threads)                                 # 0 = one worker per hardware thread (pages are independent)
     if precondition:
         o.precondition = 1
         o.format = precondition["format"]
