@@ -124,6 +124,32 @@ def cpu_baseline(streams, budget_s=12.0):
                       f"reference worker policy, host has {os.cpu_count()} logical CPUs"}, outs
 
 
+def kernel_source_hash():
+    """First 16 hex digits of the SHA-256 of the decode kernels' source: ties a profile to the build it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h"):
+        h.update(open(os.path.join(ROOT, "brotli_g_sdk_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n):
+    """Re-executes this command line under torch.distributed.run with one rank per GPU on this node
+    (rendezvous on 127.0.0.1).  Fails loudly when fewer than `n` devices are visible.  Returns the exit code."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and "--stack-ranks" not in sys.argv:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} HIP device(s) visible "
+                         "(one process per GPU; the ranks are not stacked on one device)")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,9 +164,21 @@ def main():
                     help="encoder flags for the synthetic streams (192 = optimal parse + distance parameter search; slow)")
     ap.add_argument("--preencoded", default=None,
                     help=".npz of streams made by profiles/tools/preencode.py with the same workload / distinct / flags")
+    ap.add_argument("--no-alt-parse", action="store_true",
+                    help="skip the second measurement on the same pages encoded with the optimal parse (reported as \"alt\", outside `value`)")
+    ap.add_argument("--stack-ranks", action="store_true",
+                    help="launch-path test only: ranks beyond the visible devices share them (gloo control plane, "
+                         "labelled \"stacked\" in the output; not a scaling measurement)")
     ap.add_argument("--gather", action="store_true",
                     help="N > 1: also time an all-gather of the decoded shards (reported separately, never part of `value`)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here, one process per
+    # GPU (the form `python -m torch.distributed.run ... bench.py --gpus N` arrives with WORLD_SIZE set and
+    # skips this).  The page fan-out being replaced: src/BrotligDecoder.cpp:402-416 (workers),
+    # BrotliGCompute.hlsl:1757-1881 (stream queue).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     global ENCODER_FLAGS, PREENCODED
     ENCODER_FLAGS = args.encoder_flags
@@ -153,11 +191,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU decode path in the product)")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    ndev = torch.cuda.device_count()
+    stacked = args.stack_ranks and world > ndev
+    if local_rank >= ndev and not stacked:
+        raise SystemExit(f"bench.py: rank {rank} has no device (LOCAL_RANK {local_rank}, {ndev} visible)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = f"cuda:{dev_index}"
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if stacked:
+            dist.init_process_group("gloo")             # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
     from brotli_g_sdk_amd import api, _build
 
     # the in-tree libraries are normally prebuilt; should one be stale, only one rank per node rebuilds it
@@ -199,10 +247,7 @@ def main():
         got = dec.d_out[dec.out_offs[k]:dec.out_offs[k] + dec.sizes[k]].view(-1, exp.numel())     # tiled streams: every repeat
         ok = ok and bool((got == exp.unsqueeze(0)).all())
     if world > 1:
-        import torch.distributed as dist
-        flag = torch.tensor([1 if ok else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = bool(flag.item())
+        ok = shard.min_over_ranks(1.0 if ok else 0.0) > 0.5
 
     gather_ms = None
     if args.gather and world > 1:                                       # optional exchange step, SURVEY.md 8(e)
@@ -217,8 +262,8 @@ def main():
     per_rank_c = dec.compressed_bytes
     ms_per_step = wall_ms / args.steps
     total_u = shard.sum_over_ranks(per_rank_u)
+    decoded_ranks = shard.sum_over_ranks(1 if per_rank_u > 0 else 0)
     value = total_u / (ms_per_step * 1e-3) / 1e9
-    achieved = (per_rank_u + per_rank_c) / (kernel_ms * 1e-3) / 1e9
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -227,19 +272,63 @@ def main():
         if not np.array_equal(outs[0], gpu0):
             ok = False
 
-    # HBM traffic cannot be counted from inside this process (it needs rocprofv3 --pmc passes); for the
-    # default workload the committed measurement of the same command is attached, with its source.
+    # HBM traffic cannot be counted from inside this process (it needs rocprofv3 --pmc passes).  The committed
+    # measurement of the same command is attached only when it was taken on THIS kernel source (the file
+    # records a hash of csrc/brotlig_kernels.h); a measurement of another build is dropped, not reused.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
-    if args.workload == "mixed" and args.streams == 16 and args.pages_per_stream == 4096 and os.path.exists(tpath):
-        t = json.load(open(tpath))
-        traffic = int(t["traffic_bytes_per_launch_raw"])
-        traffic_src = "profiles/r01_final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, raw KiB x 1024)"
+    ksha = kernel_source_hash()
+    if args.workload == "mixed" and args.streams == 16 and args.pages_per_stream == 4096 and distinct == 256 and not args.preencoded and not args.encoder_flags:
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+            t = json.load(open(tpath))
+            if t.get("kernel_source_sha16") == ksha:
+                traffic = int(t["traffic_bytes_per_launch_raw"])
+                traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes, "
+                               f"raw KiB x 1024; kernel source {ksha})")
+                break
+
+    # Roofline of the step's dominant kernel(s).  Plain streams: (C + U) over the decode kernel.  Pre-conditioned
+    # streams take two passes -- the page kernel writes conditioned bytes to the scratch buffer, the de-conditioning
+    # kernel reads them back and writes the texture -- so the step moves C + 3U and is priced over
+    # both kernels: the event-timed step (prepare + decode + de-condition), not the decode kernel alone.
+    roof_kernel, roof_bytes, roof_ms = "brotlig_decode_kernel", per_rank_u + per_rank_c, kernel_ms_max
+    if args.workload == "bc3":
+        roof_kernel = "brotlig_decode_kernel + brotlig_decondition_kernel (event-timed step)"
+        roof_bytes = per_rank_c + 3 * per_rank_u
+        roof_ms = shard.max_over_ranks(total_ms / args.steps)
+    achieved = roof_bytes / (roof_ms * 1e-3) / 1e9
+
+    # The same pages under the encoder's densest parse (shortest-path parse + distance parameter search): what the
+    # reference's Zopfli-based encoder (src/encoder/PageEncoder.cpp:87-147) produces resembles it more than the
+    # default lazy parse does.  Reported beside `value`, never instead of it.
+    alt = None
+    if not args.no_alt_parse and not args.no_cpu_baseline and args.workload not in ("bc3",) and not args.preencoded and world == 1:
+        from brotli_g_sdk_amd import encoder as E
+        global ENCODER_FLAGS
+        keep = ENCODER_FLAGS
+        ENCODER_FLAGS = E.OPTIMAL_PARSE | E.SEARCH_DIST_PARAMS
+        t_enc = time.perf_counter()
+        streams2, expected2 = build_streams(args.workload, mine, args.pages_per_stream, distinct)
+        t_enc = time.perf_counter() - t_enc
+        ENCODER_FLAGS = keep
+        del dec
+        torch.cuda.empty_cache()
+        dec2 = api.BatchDecoder(streams2, device=dev)
+        dec2.decode(check=True)
+        tot2, k2 = dec2.timed(1, max(2, args.steps // 2))
+        dec2.poison_output(); dec2.decode(check=True); torch.cuda.synchronize()
+        ok2 = all(bool((dec2.d_out[dec2.out_offs[k]:dec2.out_offs[k] + dec2.sizes[k]].view(-1, len(expected2[k]))
+                        == torch.from_numpy(expected2[k]).to(dev).unsqueeze(0)).all()) for k in range(len(streams2)))
+        ok = ok and ok2
+        alt = {"parse": "optimal (shortest-path parse + NPOSTFIX/NDIRECT search, encoder flags 192)",
+               "value": round(dec2.decompressed_bytes / (k2 * 1e-3) / 1e9, 3), "unit": "GB/s (decode kernel)",
+               "kernel_ms": round(k2, 4), "compression_ratio": round(dec2.decompressed_bytes / dec2.compressed_bytes, 3),
+               "bit_exact": ok2, "encode_s": round(t_enc, 1)}
 
     if rank == 0:
         line = {
             "metric": "decompressed GB/s, Brotli-G decode, bit-exact vs DecodeCPU",
-            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "GB/s", "n_gpus": world if not stacked else ndev, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "bit_exact": ok,
@@ -254,10 +343,15 @@ def main():
                        "sharding": "independent streams per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "brotlig_decode_kernel", "kernel_ms": round(kernel_ms_max, 4),
-                         "algorithmic_bytes_per_launch": per_rank_u + per_rank_c},
+                         "kernel": roof_kernel, "kernel_ms": round(roof_ms, 4),
+                         "algorithmic_bytes_per_launch": roof_bytes, "kernel_source_sha16": ksha},
             "cpu_baseline": cpu,
         }
+        if alt is not None:
+            line["alt"] = alt
+        if world > 1:
+            line["ranks"] = {"world_size": world, "backend": "gloo" if stacked else "nccl (RCCL)", "stacked": bool(stacked),
+                             "ranks_that_decoded": int(decoded_ranks)}
         if gather_ms is not None:
             line["gather"] = {"ms": round(gather_ms, 3), "what": "all-gather of the decoded shards over RCCL, outside `value`",
                               "decode_plus_gather_GBps": round(total_u / ((ms_per_step + gather_ms) * 1e-3) / 1e9, 3)}

@@ -247,14 +247,22 @@ class Streamer:
         return t.value
 
     def wait(self, ticket):
+        """Waits for the batch; its `outputs` arrays (if any were given) are filled on return.  Also valid for a
+        batch that a later submit() had to complete to make room (one generation back)."""
         rc = lib().BrotligStreamerWait(self._h, ticket)
+        outputs = self._keep.get(ticket, (0, None))[1]
+        if outputs is not None or rc != BROTLIG_OK:
+            self._keep.pop(ticket, None)            # nothing left to fetch for this ticket
         if rc != BROTLIG_OK:
             raise BrotligError(rc, "BrotligStreamerWait")
 
     def result(self, ticket):
         """Waits for the batch and returns its decoded streams as fresh arrays."""
+        n, outputs = self._keep[ticket]
         self.wait(ticket)
-        n, _ = self._keep.pop(ticket)
+        if outputs is not None:                     # the caller's own arrays hold the bytes
+            return [o for o in outputs]
+        self._keep.pop(ticket, None)
         out = []
         for i in range(n):
             sz = ctypes.c_uint32()

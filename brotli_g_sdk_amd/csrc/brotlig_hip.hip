@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "brotlig_amd.h"
@@ -34,25 +35,43 @@ uint64_t max_pages(uint32_t n, uint64_t out_bytes) { return out_bytes / kMinPage
 // Below this many pages the schedule is not worth its two extra launches (about two pages per half-wave).
 constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
 
-int g_grid = 0;
-int g_decond_grid = 1024;
-int g_order_grid = 1024;
+// Launch geometry per device (CU count x occupancy of the decode kernel), looked up once per device;
+// host threads driving different devices (or the same one) may arrive here concurrently.
+struct Grids { int decode = 0, decond = 1024, order = 1024; };
+constexpr int kMaxDevices = 64;
+std::mutex g_grid_mutex;
+Grids g_grids[kMaxDevices];
 
-BROTLIG_ERROR grid_size(int* out)
+BROTLIG_ERROR grid_sizes(Grids* out)
 {
-    if (g_grid == 0) {
-        int dev = 0, cus = 0, per_cu = 0;
-        HIP_OK(hipGetDevice(&dev));
+    int dev = 0;
+    HIP_OK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDevices) return BROTLIG_ERROR_GENERIC;
+    std::lock_guard<std::mutex> lock(g_grid_mutex);
+    Grids& g = g_grids[dev];
+    if (g.decode == 0) {
+        int cus = 0, per_cu = 0;
         HIP_OK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, brotlig_decode_kernel, 64, 0));
         if (per_cu < 1) per_cu = 1;
-        g_grid = cus * per_cu;
-        g_decond_grid = cus * 8;
-        g_order_grid = cus * 4;
+        g.decond = cus * 8;
+        g.order = cus * 4;
+        g.decode = cus * per_cu;
     }
-    *out = g_grid;
+    *out = g;
     return BROTLIG_OK;
 }
+
+// hipEvent_t that is destroyed on scope exit
+struct Event {
+    hipEvent_t e = nullptr;
+    Event() = default;
+    Event(const Event&) = delete;
+    Event& operator=(const Event&) = delete;
+    Event(Event&& o) noexcept : e(o.e) { o.e = nullptr; }
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+    hipError_t create() { return hipEventCreate(&e); }
+};
 
 DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
                      const BrotligStreamDesc* d_streams, uint32_t n, void* d_ws, size_t ws_bytes, void* d_scratch)
@@ -77,21 +96,21 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
 // prepare (page counts -> prefix) then the persistent page-decode kernel; k0/k1 bracket the latter
 BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
 {
-    int grid = 0;
-    if (BROTLIG_ERROR e = grid_size(&grid)) return e;
+    Grids g;
+    if (BROTLIG_ERROR e = grid_sizes(&g)) return e;
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), s));
     hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(1), dim3(64), 0, s, a);
     if (a.order) {                                                      // page schedule: count, then scatter
-        hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g_order_grid), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g_order_grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g.order), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, s, a);
     }
     hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, s, a);
     if (k0) HIP_OK(hipEventRecord(k0, s));
-    hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, s, a);
     if (k1) HIP_OK(hipEventRecord(k1, s));
     {   // streams over y, each stream's tiles over x; about 8 workgroups of 256 per CU in total
         const unsigned gy = a.num_streams < 32u ? a.num_streams : 32u;
-        const unsigned gx = ((unsigned)g_decond_grid + gy - 1u) / gy;
+        const unsigned gx = ((unsigned)g.decond + gy - 1u) / gy;
         hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(gx, gy), dim3(256), 0, s, a);
     }
     HIP_OK(hipGetLastError());
@@ -156,19 +175,18 @@ extern "C" BROTLIG_ERROR BrotligDecodeBatchTimed(const void* d_in, uint64_t in_b
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, ws_bytes, d_scratch);
     for (uint32_t i = 0; i < warmup; ++i) if (BROTLIG_ERROR e = enqueue(a, s, nullptr, nullptr)) return e;
-    std::vector<hipEvent_t> ev(2 * (size_t)steps + 2);
-    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
-    HIP_OK(hipEventRecord(ev[2 * steps], s));
-    for (uint32_t i = 0; i < steps; ++i) if (BROTLIG_ERROR e = enqueue(a, s, ev[2 * i], ev[2 * i + 1])) return e;
-    HIP_OK(hipEventRecord(ev[2 * steps + 1], s));
+    std::vector<Event> ev(2 * (size_t)steps + 2);
+    for (auto& e : ev) HIP_OK(e.create());
+    HIP_OK(hipEventRecord(ev[2 * steps].e, s));
+    for (uint32_t i = 0; i < steps; ++i) if (BROTLIG_ERROR e = enqueue(a, s, ev[2 * i].e, ev[2 * i + 1].e)) return e;
+    HIP_OK(hipEventRecord(ev[2 * steps + 1].e, s));
     HIP_OK(hipStreamSynchronize(s));
     float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, ev[2 * steps], ev[2 * steps + 1]));
+    HIP_OK(hipEventElapsedTime(&ms, ev[2 * steps].e, ev[2 * steps + 1].e));
     if (total_ms) *total_ms = ms;
     double ksum = 0.0;
-    for (uint32_t i = 0; i < steps; ++i) { HIP_OK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); ksum += ms; }
+    for (uint32_t i = 0; i < steps; ++i) { HIP_OK(hipEventElapsedTime(&ms, ev[2 * i].e, ev[2 * i + 1].e)); ksum += ms; }
     if (decode_kernel_ms) *decode_kernel_ms = ksum / steps;
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return BROTLIG_OK;
 }
 
@@ -200,15 +218,14 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
     HIP_OK(hipMemcpy(d_in.p, input, input_size, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_desc.p, &desc, sizeof desc, hipMemcpyHostToDevice));
 
-    hipEvent_t e0, e1;
-    HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    Event e0, e1;
+    HIP_OK(e0.create()); HIP_OK(e1.create());
     const DecodeArgs a = make_args(d_in.p, input_size, d_out.p, out_alloc, static_cast<BrotligStreamDesc*>(d_desc.p), 1,
                                    d_ws.p, ws_size, d_scratch.p);
-    BROTLIG_ERROR err = enqueue(a, nullptr, e0, e1);
+    BROTLIG_ERROR err = enqueue(a, nullptr, e0.e, e1.e);
     if (err == BROTLIG_OK) err = BrotligDecodeBatchStatus(d_ws.p, nullptr);
     float ms = 0.f;
-    if (err == BROTLIG_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err == BROTLIG_OK && hipEventElapsedTime(&ms, e0.e, e1.e) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
     if (err != BROTLIG_OK) return err;
     HIP_OK(hipMemcpy(output, d_out.p, out_size, hipMemcpyDeviceToHost));
     *output_size = out_size;                                            // src/BrotligDecoder.cpp:490
@@ -256,8 +273,8 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
 {
     if (!d_in || !d_out || !d_streams || !d_workspace || num_streams == 0 || !cycles_out) return BROTLIG_ERROR_GENERIC;
     if (ws_bytes < workspace_bytes(num_streams)) return BROTLIG_ERROR_GENERIC;
-    int grid = 0;
-    if (BROTLIG_ERROR e = grid_size(&grid)) return e;
+    Grids g;
+    if (BROTLIG_ERROR e = grid_sizes(&g)) return e;
     DevBuf prof;
     HIP_OK(hipMalloc(&prof.p, kNumPhases * sizeof(unsigned long long)));
     HIP_OK(hipMemset(prof.p, 0, kNumPhases * sizeof(unsigned long long)));
@@ -266,11 +283,11 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), nullptr));
     hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(1), dim3(64), 0, nullptr, a);
     if (a.order) {
-        hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g_order_grid), dim3(64), 0, nullptr, a);
-        hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g_order_grid), dim3(64), 0, nullptr, a);
+        hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g.order), dim3(64), 0, nullptr, a);
+        hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, nullptr, a);
     }
     hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, nullptr, a);
-    hipLaunchKernelGGL(brotlig_decode_kernel_timed, dim3(grid), dim3(64), 0, nullptr, a);
+    hipLaunchKernelGGL(brotlig_decode_kernel_timed, dim3(g.decode), dim3(64), 0, nullptr, a);
     HIP_OK(hipDeviceSynchronize());
     unsigned long long h[kNumPhases];
     HIP_OK(hipMemcpy(h, prof.p, sizeof h, hipMemcpyDeviceToHost));
@@ -279,4 +296,4 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
 }
 
 extern "C" uint32_t BrotligKernelLdsBytes(void) { return (uint32_t)sizeof(WaveLds); }
-extern "C" uint32_t BrotligKernelGridSize(void) { int g = 0; return grid_size(&g) == BROTLIG_OK ? (uint32_t)g : 0u; }
+extern "C" uint32_t BrotligKernelGridSize(void) { Grids g; return grid_sizes(&g) == BROTLIG_OK ? (uint32_t)g.decode : 0u; }

@@ -1285,7 +1285,12 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
     t.pitch[0] = ((w1 >> 13) & 0x7FFFFu) + 1u;
     uint32_t mw = (t.w[0] * px) / 2u, mh = (t.h[0] * px) / 2u;
     t.mip_off_bytes[0] = 0; t.mip_off_blocks[0] = 0; t.item_prefix[0] = 0;
-    uint32_t total = 0;
+    // All sizes are accumulated in 64 bits and must stay inside the stream's output: the header fields are
+    // 15 + 15 + 19 bits wide, so pitch * h alone can pass 2^32 (the reference computes in 32 bits and would
+    // wrap, inc/common/BrotligDataConditioner.h:204-219; a wrapped total that happens to equal out_size must
+    // not be accepted, the de-conditioning kernel walks the real rows).
+    uint64_t total = 0, bytes = 0, items = 0;
+    bool fits = true;
     for (uint32_t m = 0; m < t.num_mips; ++m) {
         if (m > 0u) {                                                   // :204-210
             t.w[m] = (mw + px - 1u) / px; t.h[m] = (mh + px - 1u) / px;
@@ -1293,18 +1298,21 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
             t.pitch[m] = aligned ? (row + 255u) / 256u * 256u : row;
             mw /= 2u; mh /= 2u;
         }
-        const uint32_t nblk = t.w[m] * t.h[m];
-        total += nblk;
-        t.mip_off_bytes[m + 1] = t.mip_off_bytes[m] + t.pitch[m] * t.h[m];
-        t.mip_off_blocks[m + 1] = t.mip_off_blocks[m] + nblk;
-        t.item_prefix[m + 1] = t.item_prefix[m] + ((t.h[m] + 1u) / 2u) * (((t.pitch[m] + bb - 1u) / bb + 31u) / 32u) * 64u;
+        if ((uint64_t)t.pitch[m] < (uint64_t)t.w[m] * bb) fits = false;
+        total += (uint64_t)t.w[m] * t.h[m];
+        bytes += (uint64_t)t.pitch[m] * t.h[m];
+        items += (uint64_t)((t.h[m] + 1u) / 2u) * (((t.pitch[m] + bb - 1u) / bb + 31u) / 32u) * 64u;
+        if (bytes > (uint64_t)out_size || total * bb > (uint64_t)out_size || items > 0xFFFFFFFFull) fits = false;
+        t.mip_off_bytes[m + 1] = fits ? (uint32_t)bytes : 0u;
+        t.mip_off_blocks[m + 1] = fits ? (uint32_t)total : 0u;
+        t.item_prefix[m + 1] = fits ? (uint32_t)items : 0u;
     }
     for (uint32_t m = t.num_mips; m < kMaxMips; ++m) { t.w[m] = t.h[m] = t.pitch[m] = 0; }
-    t.total_blocks = total; t.tex_bytes = total * bb;
+    if (!fits) return false;
+    t.total_blocks = (uint32_t)total; t.tex_bytes = (uint32_t)(total * bb);
     t.sub_stream_off[0] = 0;
-    for (uint32_t i = 0; i < kMaxSubBlocks; ++i) t.sub_stream_off[i + 1] = t.sub_stream_off[i] + total * t.sub_size[i];
-    if (t.pitch[0] < t.w[0] * bb) return false;
-    return t.mip_off_bytes[t.num_mips] == out_size;                     // :219
+    for (uint32_t i = 0; i < kMaxSubBlocks; ++i) t.sub_stream_off[i + 1] = t.sub_stream_off[i] + t.total_blocks * t.sub_size[i];
+    return bytes == (uint64_t)out_size;                                 // :219
 }
 
 // Kernel 3 (preconditioned streams only): conditioned space -> texture space, as a gather.
@@ -1433,7 +1441,11 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
             DcTable& t = a.dc[s];
             t.precon = 0;
             if (pages && si.preconditioned) {
-                if (!dc_init(t, load_u32(p + 8), load_u32(p + 12), uncompressed_size(si)) || a.scratch == nullptr) {
+                // the texture must also lie inside the caller's output buffer: the de-conditioning kernel writes
+                // all of it, whatever happened to the stream's pages
+                const uint64_t usz = uncompressed_size(si);
+                if (in_off + 16u > a.in_bytes || a.scratch == nullptr || a.streams[s].out_offset + usz > a.out_bytes ||
+                    !dc_init(t, load_u32(p + 8), load_u32(p + 12), (uint32_t)usz)) {
                     t.precon = 0; pages = 0;                            // the reference has undefined behaviour here
                     atomicOr(a.status, kStatusBadHeader);
                 } else atomicAdd(a.status + 2, 1u);

@@ -50,6 +50,10 @@ struct Slot {
     std::vector<uint32_t> out_size;
     std::vector<uint8_t*> user_out;
     BROTLIG_ERROR result = BROTLIG_OK;
+    // the batch this slot held before the current one, when Submit had to complete it to make room:
+    // its result stays available to Wait (its outputs[] were filled at that point)
+    uint64_t evicted_ticket = 0;
+    BROTLIG_ERROR evicted_result = BROTLIG_OK;
 };
 
 }  // namespace
@@ -148,14 +152,11 @@ extern "C" BROTLIG_ERROR BrotligStreamerSubmit(BrotligStreamer* st, uint32_t n, 
                                                const uint32_t* output_caps, uint64_t* ticket)
 {
     if (!st || !inputs || !input_sizes || !ticket || n == 0 || n > st->max_streams) return BROTLIG_ERROR_GENERIC;
-    Slot& s = st->slots[st->next_ticket % st->num_slots];
-    if (s.busy) (void)finish(s);                                        // ring full: the oldest batch completes first
-                                                                        // (its result stays readable through Wait)
-    s.ticket = 0; s.n = 0;                                              // the slot's previous batch is gone from here on
-    // ---- validate the headers (src/BrotligDecoder.cpp:437-446) and lay the batch out
-    s.out_off.assign(n, 0); s.out_size.assign(n, 0); s.user_out.assign(n, nullptr);
-    BrotligStreamDesc* desc = reinterpret_cast<BrotligStreamDesc*>(s.h_in + st->slot_in);
-    uint64_t in_pos = 0, out_pos = 0;
+    // ---- validate the headers (src/BrotligDecoder.cpp:437-446) and lay the batch out, without touching the
+    //      slot: a refused batch must leave the ring (and the batch it would have displaced) as it was
+    std::vector<uint64_t> in_off(n), out_off(n);
+    std::vector<uint32_t> out_size(n);
+    uint64_t in_pos = 0, out_pos = 0, sum_in = 0, sum_out = 0;
     bool precon = false;
     for (uint32_t i = 0; i < n; ++i) {
         if (!inputs[i] || input_sizes[i] < 12) return BROTLIG_ERROR_CORRUPT_STREAM;
@@ -169,30 +170,60 @@ extern "C" BROTLIG_ERROR BrotligStreamerSubmit(BrotligStreamer* st, uint32_t n, 
         const uint64_t in_need = align_up(input_sizes[i], kAlign);
         const uint64_t out_need = align_up((uint64_t)si.num_pages * si.page_size, kAlign);
         if (in_pos + in_need > st->slot_in || out_pos + out_need > st->slot_out) return BROTLIG_ERROR_GENERIC;   // batch too big for a slot
-        memcpy(s.h_in + in_pos, inputs[i], input_sizes[i]);
-        memset(s.h_in + in_pos + input_sizes[i], 0, in_need - input_sizes[i]);
-        desc[i].in_offset = in_pos; desc[i].out_offset = out_pos;
-        s.out_off[i] = out_pos; s.out_size[i] = usize; s.user_out[i] = outputs ? outputs[i] : nullptr;
+        in_off[i] = in_pos; out_off[i] = out_pos; out_size[i] = usize;
         in_pos += in_need; out_pos += out_need;
         precon = precon || si.preconditioned;
-        st->bytes_in += input_sizes[i]; st->bytes_out += usize;
+        sum_in += input_sizes[i]; sum_out += usize;
+    }
+
+    Slot& s = st->slots[st->next_ticket % st->num_slots];
+    if (s.busy || s.ticket != 0) {
+        // ring full (or the slot's last batch was never waited for): that batch completes now -- its outputs[]
+        // are filled -- and its result is kept for a later Wait on its ticket
+        s.evicted_result = finish(s);
+        s.evicted_ticket = s.ticket;
     }
     if (precon && !s.d_scratch) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.d_scratch), st->slot_out + 64));
+    s.ticket = 0; s.n = 0;                                              // the slot's pinned bytes are overwritten from here on
+    s.out_off = out_off; s.out_size = out_size; s.user_out.assign(n, nullptr);
+    BrotligStreamDesc* desc = reinterpret_cast<BrotligStreamDesc*>(s.h_in + st->slot_in);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t in_need = align_up(input_sizes[i], kAlign);
+        memcpy(s.h_in + in_off[i], inputs[i], input_sizes[i]);
+        memset(s.h_in + in_off[i] + input_sizes[i], 0, in_need - input_sizes[i]);
+        desc[i].in_offset = in_off[i]; desc[i].out_offset = out_off[i];
+        s.user_out[i] = outputs ? outputs[i] : nullptr;
+    }
 
-    // ---- upload, decode, download: all on the slot's stream
+    // ---- upload, decode, download: all on the slot's stream.  Should an enqueue fail half way, whatever was
+    //      already queued is drained before the slot is handed back (the next batch reuses its pinned memory).
     const uint64_t desc_bytes = sizeof(BrotligStreamDesc) * (uint64_t)n;
-    HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, in_pos, hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(hipMemcpyAsync(s.d_in + st->slot_in, desc, desc_bytes, hipMemcpyHostToDevice, s.stream));
-    const BROTLIG_ERROR e = BrotligDecodeBatchDevice(s.d_in, in_pos, s.d_out, out_pos,
-                                                     reinterpret_cast<const BrotligStreamDesc*>(s.d_in + st->slot_in), n,
-                                                     s.d_ws, st->ws_bytes, precon ? s.d_scratch : nullptr, s.stream);
-    if (e != BROTLIG_OK) return e;
-    HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, out_pos, hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(hipMemcpyAsync(s.h_status, s.d_ws, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(hipEventRecord(s.done, s.stream));
+    BROTLIG_ERROR e = BROTLIG_OK;
+    auto hip_ok = [&e](hipError_t r, const char* what) {
+        if (r != hipSuccess && e == BROTLIG_OK) {
+            fprintf(stderr, "brotlig_streamer: %s failed: %s\n", what, hipGetErrorString(r));
+            e = BROTLIG_ERROR_GENERIC;
+        }
+        return e == BROTLIG_OK;
+    };
+    if (hip_ok(hipMemcpyAsync(s.d_in, s.h_in, in_pos, hipMemcpyHostToDevice, s.stream), "upload") &&
+        hip_ok(hipMemcpyAsync(s.d_in + st->slot_in, desc, desc_bytes, hipMemcpyHostToDevice, s.stream), "descriptor upload")) {
+        e = BrotligDecodeBatchDevice(s.d_in, in_pos, s.d_out, out_pos,
+                                     reinterpret_cast<const BrotligStreamDesc*>(s.d_in + st->slot_in), n,
+                                     s.d_ws, st->ws_bytes, precon ? s.d_scratch : nullptr, s.stream);
+        if (e == BROTLIG_OK) {
+            hip_ok(hipMemcpyAsync(s.h_out, s.d_out, out_pos, hipMemcpyDeviceToHost, s.stream), "download") &&
+            hip_ok(hipMemcpyAsync(s.h_status, s.d_ws, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream), "status download") &&
+            hip_ok(hipEventRecord(s.done, s.stream), "event record");
+        }
+    }
+    if (e != BROTLIG_OK) {
+        (void)hipStreamSynchronize(s.stream);
+        return e;
+    }
     s.busy = true; s.n = n; s.ticket = st->next_ticket; s.result = BROTLIG_OK;
     *ticket = st->next_ticket++;
-    ++st->batches;
+    ++st->batches; st->bytes_in += sum_in; st->bytes_out += sum_out;
     return BROTLIG_OK;
 }
 
@@ -200,8 +231,9 @@ extern "C" BROTLIG_ERROR BrotligStreamerWait(BrotligStreamer* st, uint64_t ticke
 {
     if (!st || ticket == 0 || ticket >= st->next_ticket) return BROTLIG_ERROR_GENERIC;
     Slot& s = st->slots[ticket % st->num_slots];
-    if (s.ticket != ticket) return BROTLIG_ERROR_GENERIC;               // the slot has been reused since
-    return finish(s);
+    if (s.ticket == ticket) return finish(s);
+    if (s.evicted_ticket == ticket) return s.evicted_result;            // completed by a later Submit; outputs[] are filled
+    return BROTLIG_ERROR_GENERIC;                                       // more than one generation old: forgotten
 }
 
 extern "C" const uint8_t* BrotligStreamerOutput(BrotligStreamer* st, uint64_t ticket, uint32_t index, uint32_t* size)

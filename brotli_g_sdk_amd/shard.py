@@ -27,6 +27,10 @@ def max_over_ranks(value):
     return _reduce(value, "MAX")
 
 
+def min_over_ranks(value):
+    return _reduce(value, "MIN")
+
+
 def sum_over_ranks(value):
     return int(_reduce(value, "SUM"))
 

@@ -132,10 +132,13 @@ BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in_bytes, voi
  * (upload k+1 | decode k | download k-1).  One host thread per streamer; no global state.
  *   slot_in_bytes / slot_out_bytes: capacity of one batch (sum of stream sizes / of NumPages*PageSize).
  *   Submit copies the streams into pinned memory and returns at once with a ticket (it blocks only
- *   when every slot is in flight: then the oldest batch is completed first).  outputs[i] may be NULL
- *   (or `outputs` itself NULL): the decoded bytes then stay in the slot's pinned buffer, readable
- *   through BrotligStreamerOutput until the slot is reused (num_slots submissions later).
- *   Wait returns the batch's result (BROTLIG_OK / CORRUPT_STREAM / GENERIC) after copying to outputs[]. */
+ *   when every slot is in flight: then the oldest batch is completed first -- its outputs[] are filled and
+ *   its result stays available to one later Wait).  A batch that Submit refuses (bad header, too large)
+ *   leaves the ring untouched.  outputs[i] may be NULL (or `outputs` itself NULL): the decoded bytes then
+ *   stay in the slot's pinned buffer, readable through BrotligStreamerOutput until the slot is reused
+ *   (num_slots submissions later; after that Output returns NULL).
+ *   Wait returns the batch's result (BROTLIG_OK / CORRUPT_STREAM / GENERIC) after copying to outputs[];
+ *   for a batch displaced by a later Submit it returns the result recorded then (one generation back). */
 typedef struct BrotligStreamer BrotligStreamer;
 BROTLIG_ERROR BrotligStreamerCreate(uint32_t num_slots, uint64_t slot_in_bytes, uint64_t slot_out_bytes,
                                     uint32_t max_streams_per_batch, BrotligStreamer** out);

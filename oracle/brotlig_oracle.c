@@ -321,6 +321,22 @@ uint32_t brotlig_oracle_decondition_addr(uint32_t w0, uint32_t w1, uint32_t out_
     return decondition_addr(&dc, p - dc.sub_stream_off[sub], sub);
 }
 
+/* Test helper: the per-format layout dc_init derives (inc/common/BrotligDataConditioner.h:96-183), for the
+ * KAT against the reference's BROTLIG_BC*_ macros.  out[0] block bytes, [1] block pixels, [2] sub-blocks,
+ * [3..8] sub-block sizes, [9] colour sub-block count, [10..13] colour sub-blocks, [14] total blocks.
+ * Returns 0 when the header does not describe out_size bytes. */
+int brotlig_oracle_dc_layout(uint32_t w0, uint32_t w1, uint32_t out_size, uint32_t out[15])
+{
+    DcParams dc; dc_from_header(&dc, w0, w1);
+    if (!dc_init(&dc, out_size)) return 0;
+    out[0] = dc.block_bytes; out[1] = dc.block_px; out[2] = dc.num_sub;
+    for (uint32_t i = 0; i < 6; ++i) out[3 + i] = dc.sub_size[i];
+    out[9] = dc.num_color;
+    for (uint32_t i = 0; i < 4; ++i) out[10 + i] = dc.color_sub[i];
+    out[14] = dc.total_blocks;
+    return 1;
+}
+
 /* ------------------------------------------------------------------------ */
 /* Page decoder (src/decoder/PageDecoder.cpp)                                */
 

@@ -74,6 +74,12 @@ void brotlig_oracle_cmd_lut(uint32_t sym, uint32_t* ins_extra, uint32_t* copy_ex
  * Returns 0xFFFFFFFF when p is not covered by any block. Test helper. */
 uint32_t brotlig_oracle_decondition_addr(uint32_t w0, uint32_t w1, uint32_t out_size, uint32_t p);
 
+/* Per-format layout derived by the restatement of BrotligDataconditionParams::Initialize
+ * (inc/common/BrotligDataConditioner.h:96-183): out[0] block bytes, [1] block pixels, [2] sub-blocks,
+ * [3..8] sub-block sizes, [9] colour sub-block count, [10..13] colour sub-blocks, [14] total blocks.
+ * Returns 0 when (w0, w1) does not describe a texture of out_size bytes.  Test helper. */
+int brotlig_oracle_dc_layout(uint32_t w0, uint32_t w1, uint32_t out_size, uint32_t out[15]);
+
 #ifdef __cplusplus
 }
 #endif

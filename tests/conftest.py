@@ -12,6 +12,28 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _hip_device_usable():
+    if not os.path.exists("/dev/kfd"):
+        return False
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped (not failed) on a machine without a usable HIP device, so that a plain
+    `pytest tests` is green in the build container; on the GPU box they run and fail loudly if the HIP
+    library is missing (there is no CPU decode path to fall back to)."""
+    gpu_items = [it for it in items if it.get_closest_marker("gpu") is not None]
+    if not gpu_items or _hip_device_usable():
+        return
+    skip = pytest.mark.skip(reason="no usable HIP device (gpu tests run on the MI355X box)")
+    for it in gpu_items:
+        it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from helpers import oracle_lib

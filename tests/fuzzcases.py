@@ -1,0 +1,126 @@
+"""Seeded random stream generators shared by the simulator tests (CPU) and the on-device differential and
+negative tests (-m gpu): random data compositions x random encoder options x random pre-conditioning
+parameters, and corrupted variants (bit flips, truncation, header damage)."""
+import numpy as np
+
+from brotli_g_sdk_amd import datagen as D
+from brotli_g_sdk_amd import encoder as E
+
+
+def compose(seed, n):
+    """Random mix of literal stretches, byte runs, self-overlapping short periods, near and far repeats."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(n + 70000, np.uint8)
+    pos = 0
+    while pos < n:
+        kind = rng.integers(0, 8)
+        if kind == 0 or pos < 16:                                   # fresh literals
+            k = int(rng.integers(1, 200))
+            out[pos:pos + k] = rng.integers(0, 256, k, dtype=np.uint8)
+        elif kind == 1:                                             # byte run (distance 1)
+            k = int(rng.integers(2, 3000))
+            out[pos:pos + k] = out[pos - 1]
+        elif kind == 2:                                             # short period, self-overlapping
+            d = int(rng.integers(2, 40)); k = int(rng.integers(d, 2500))
+            for i in range(k):
+                out[pos + i] = out[pos + i - d]
+        elif kind == 3:                                             # near repeat
+            d = int(rng.integers(1, min(pos, 1500))) if pos > 1 else 1
+            k = int(rng.integers(2, 64)); k = min(k, d)
+            out[pos:pos + k] = out[pos - d:pos - d + k]
+        elif kind == 4:                                             # far repeat, short
+            d = int(rng.integers(1, pos + 1)); k = int(min(rng.integers(2, 40), d))
+            out[pos:pos + k] = out[pos - d:pos - d + k]
+        elif kind == 5:                                             # far repeat, long
+            d = int(rng.integers(1, pos + 1)); k = int(min(rng.integers(40, 4000), d))
+            out[pos:pos + k] = out[pos - d:pos - d + k]
+        elif kind == 7:                                             # long literal stretch (crosses assembly groups)
+            k = int(rng.integers(500, 5000))
+            out[pos:pos + k] = rng.integers(0, 256, k, dtype=np.uint8)
+        else:                                                       # skewed literals
+            k = int(rng.integers(1, 400))
+            out[pos:pos + k] = np.minimum(rng.geometric(0.3, k) - 1, 255)
+        pos += k
+    return out[:n].copy()
+
+
+_FLAG_CHOICES = [0, 0, 0, E.NO_CODELEN_RLE, E.NO_RING_CODES, E.NO_LAZY, E.LITERALS_ONLY, E.FORCE_COMPLEX_TABLES,
+                 E.SEARCH_DIST_PARAMS, E.OPTIMAL_PARSE, E.OPTIMAL_PARSE | E.SEARCH_DIST_PARAMS, E.NO_LAZY | E.NO_RING_CODES]
+
+
+def random_plain(seed):
+    """(data, encoder kwargs) for the seed: size 1 .. ~3 pages, any data class, any option set."""
+    rng = np.random.default_rng(77000 + seed)
+    page_size = int(rng.choice([32768, 65536, 65536, 131072]))
+    n = int(rng.integers(1, 3 * page_size)) if rng.integers(0, 4) else int(rng.integers(1, 600))
+    kind = int(rng.integers(0, 8))
+    if kind == 0:
+        data = compose(seed, n)
+    elif kind == 1:
+        data = D.text(n, seed)
+    elif kind == 2:
+        data = D.records(n, seed)
+    elif kind == 3:
+        data = D.samples16(n, seed)
+    elif kind == 4:
+        data = D.runs(n, seed)
+    elif kind == 5:
+        data = D.mixed(n, seed)
+    elif kind == 6:
+        data = np.minimum(rng.geometric(float(rng.uniform(0.05, 0.6)), n) - 1, 255).astype(np.uint8)
+    else:
+        data = D.random_bytes(n, seed) if rng.integers(0, 2) else np.full(n, int(rng.integers(0, 256)), np.uint8)
+    npostfix = int(rng.integers(0, 4))
+    kw = dict(page_size=page_size, npostfix=npostfix, ndirect_m=int(rng.integers(0, 16)),
+              flags=int(_FLAG_CHOICES[int(rng.integers(0, len(_FLAG_CHOICES)))]))
+    if rng.integers(0, 3) == 0:
+        kw["max_chain"] = int(rng.integers(1, 64))
+    return np.ascontiguousarray(data, dtype=np.uint8), kw
+
+
+def random_precon(seed):
+    """(texture bytes, precondition dict, encoder kwargs) with random format, size, mips, swizzle, delta, pitch."""
+    rng = np.random.default_rng(88000 + seed)
+    fmt = int(rng.integers(1, 6))
+    bb = 8 if fmt in (1, 4) else 16
+    w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+    mips = int(rng.integers(1, 5)) if min(w, h) >= 8 else 1
+    aligned = int(rng.integers(0, 2)) if mips > 1 else 0
+    pitch = 0
+    if mips == 1 and rng.integers(0, 3) == 0:
+        pitch = w * bb + int(rng.integers(1, 40))
+    pre = dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=int(rng.integers(0, 2)),
+               delta=int(rng.integers(0, 2)), pitch_d3d12_aligned=aligned, pitch_bytes=pitch)
+    tex = D.bc_texture(fmt, w, h, seed=seed, num_mips=mips, aligned=bool(aligned), pitch_bytes=pitch)
+    kw = dict(page_size=int(rng.choice([32768, 65536])), flags=int(rng.choice([0, 0, E.NO_LAZY, E.SEARCH_DIST_PARAMS])))
+    return tex, pre, kw
+
+
+def corrupt(stream, seed):
+    """A damaged copy of `stream`: bit flips anywhere after the stream id, truncation, page-table damage or
+    (for pre-conditioned streams) damage to the precondition header.  Returns (bytes, kind)."""
+    rng = np.random.default_rng(99000 + seed)
+    s = stream.copy()
+    kind = ["flips", "flips", "truncate", "table", "precon_header", "page_header"][int(rng.integers(0, 6))]
+    precon = bool((int(s[6]) >> 4) & 1)
+    hdr = 16 if precon else 8
+    npages = int(s[2]) | (int(s[3]) << 8)
+    if kind == "precon_header" and not precon:
+        kind = "flips"
+    if kind == "flips":
+        for _ in range(int(rng.integers(1, 8))):
+            pos = int(rng.integers(2, len(s)))
+            s[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    elif kind == "truncate":
+        s = s[:int(rng.integers(8, len(s)))].copy() if len(s) > 9 else s
+    elif kind == "table":
+        pos = hdr + int(rng.integers(0, 4 * npages))
+        s[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    elif kind == "precon_header":
+        for _ in range(int(rng.integers(1, 4))):
+            s[8 + int(rng.integers(0, 8))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    else:                                                           # first bytes of a page: header + size table
+        first = hdr + 4 * npages
+        if first + 8 < len(s):
+            s[first + int(rng.integers(0, 8))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    return s, kind

@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE: runs the HIP decode kernels (brotli_g_sdk_amd/csrc/brotlig_kernels.h) on
 // the CPU simulator.  Built as a shared library and driven from tests/test_sim_decode.py.
+#include <cstring>
 #include <vector>
 
 #include <brotlig_wave_ops.h>
@@ -48,3 +49,20 @@ extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word
 extern "C" void sim_set_order(int on) { g_use_order = on; }
 extern "C" void sim_selftest(uint32_t* out) { sim::run_grid(1, selftest_body, out); }
 extern "C" uint64_t sim_collectives() { return sim::g_wave.n_collectives; }
+
+// The kernels' own view of the two headers, for the constant checks of tests/test_reference_kats.py.
+extern "C" int sim_dc_table(uint32_t w0, uint32_t w1, uint32_t out_size, uint32_t* words /* sizeof(DcTable) / 4 */)
+{
+    DcTable t{};
+    const bool ok = dc_init(t, w0, w1, out_size);
+    memcpy(words, &t, sizeof t);
+    return ok ? 1 : 0;
+}
+extern "C" int sim_stream_header(uint32_t w0, uint32_t w1, uint32_t out[6])
+{
+    StreamInfo si;
+    const bool ok = parse_stream_header(w0, w1, si);
+    out[0] = si.num_pages; out[1] = si.page_size; out[2] = si.last_page_size; out[3] = si.preconditioned;
+    out[4] = si.header_bytes; out[5] = uncompressed_size(si);
+    return ok ? 1 : 0;
+}

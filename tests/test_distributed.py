@@ -120,3 +120,79 @@ def test_scatter_streams_and_gather_outputs():
         assert p.exitcode == 0
     expect = hashlib.sha256(np.concatenate([D.mixed(65536 + 1000 * k, 300 + k) for k in range(5)]).tobytes()).hexdigest()
     assert digest == expect
+
+
+# ---- the product path under more than one rank (GPU box) ------------------------------------------------------
+import pytest  # noqa: E402
+
+
+def _gpu_rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from brotli_g_sdk_amd import api, datagen as D, encoder as E, shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; RCCL refuses two ranks on one device
+    torch.cuda.set_device(0)
+    n_total = 7
+    mine = shard.stream_indices(n_total, world, rank)
+    datas = {k: D.mixed(3 * 65536 + 1000 * k, 400 + k) for k in mine}
+    dec = api.BatchDecoder([E.encode(datas[k]) for k in mine], device="cuda:0")      # the HIP path, not the oracle
+    dec.poison_output()
+    dec.decode()
+    digests = torch.zeros(n_total, 32, dtype=torch.uint8)
+    for i, k in enumerate(mine):
+        out = dec.output(i)
+        assert np.array_equal(out, datas[k])
+        digests[k] = torch.frombuffer(bytearray(hashlib.sha256(out.tobytes()).digest()), dtype=torch.uint8)
+    total = shard.sum_over_ranks(dec.decompressed_bytes)
+    ranks = shard.sum_over_ranks(1)
+    dist.all_reduce(digests, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        q.put((total, ranks, digests.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_decode_their_shards_on_the_device():
+    """Two processes, each decoding its shard.stream_indices slice through the C ABI on cuda:0 (the box has one
+    GPU; the ranks share it, with a gloo control plane).  What the ranks produce together equals the source."""
+    from brotli_g_sdk_amd import datagen as D
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    total, ranks, blob = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ranks == 2
+    assert total == sum(3 * 65536 + 1000 * k for k in range(7))
+    assert blob == b"".join(hashlib.sha256(D.mixed(3 * 65536 + 1000 * k, 400 + k).tobytes()).digest() for k in range(7))
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks (torch.distributed.run on 127.0.0.1).
+    With one device on the box the ranks are stacked on it (--stack-ranks: launch-path test, labelled as such);
+    without that flag and with fewer devices than ranks it refuses instead of printing an n_gpus it did not use."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "2",
+            "--pages-per-stream", "256", "--distinct", "64", "--no-cpu-baseline"]
+    r = subprocess.run(base + ["--stack-ranks"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["bit_exact"] is True
+    assert line["ranks"]["world_size"] == 2 and line["ranks"]["ranks_that_decoded"] == 2
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert line["ranks"]["stacked"] is True and line["n_gpus"] == torch.cuda.device_count()
+        r = subprocess.run(base, capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "only 1 HIP device" in (r.stderr + r.stdout)

@@ -225,3 +225,34 @@ def test_page_schedule_large_batch(api):
         assert np.array_equal(outs[0][i].reshape(32, -1), np.broadcast_to(d, (32, len(d))))
         assert np.array_equal(outs[0][i], outs[1][i])
     assert np.array_equal(outs[0][4], tex) and np.array_equal(outs[1][4], tex)
+
+
+@pytest.mark.gpu
+def test_streamer_ring_overflow_keeps_results(api):
+    """More batches submitted than there are slots before anything is waited for: Submit completes the oldest
+    batch to make room, fills its outputs[] and keeps its result for a later Wait.  A refused batch
+    (bad header) must not disturb the batch whose slot it would have taken."""
+    slots = 2
+    st = api.Streamer(slots=slots, slot_in_bytes=2 << 20, slot_out_bytes=4 << 20, max_streams=8)
+    datas = [[D.mixed(65536 + 777 * b, 500 + b), D.text(30000 + b, 600 + b)] for b in range(5)]
+    streams = [[E.encode(d) for d in batch] for batch in datas]
+    outs = [[np.full(len(d), 0xAB, np.uint8) for d in batch] for batch in datas]
+    tickets = [st.submit(streams[b], outs[b]) for b in range(3)]            # batch 0 is displaced by batch 2
+    bad = streams[0][0].copy(); bad[1] ^= 0xFF
+    with pytest.raises(api.BrotligError):
+        st.submit([bad])                                                    # refused: the ring stays as it was
+    st.wait(tickets[0])                                                     # displaced batch: result still available
+    for d, o in zip(datas[0], outs[0]):
+        assert np.array_equal(o, d)
+    tickets.append(st.submit(streams[3], outs[3]))                          # displaces batch 1
+    tickets.append(st.submit(streams[4], None))                             # displaces batch 2; bytes stay pinned
+    for b in (1, 2, 3):
+        st.wait(tickets[b])
+        for d, o in zip(datas[b], outs[b]):
+            assert np.array_equal(o, d), b
+    got = st.result(tickets[4])
+    for d, o in zip(datas[4], got):
+        assert np.array_equal(o, d)
+    with pytest.raises(api.BrotligError):                                   # two generations back: forgotten
+        st.wait(tickets[0])
+    st.close()

@@ -1,0 +1,150 @@
+"""On-device differential and negative tests: seeded random streams -- random data
+compositions, encoder flags, page sizes, NPOSTFIX / NDIRECT, pre-conditioning parameters -- through the
+HIP path (C ABI, BrotligDecodeBatchDevice / DecodeGPU) against the CPU oracle, bit-exact; and damaged
+streams, which must come back as a status (the reference only checks the two header bytes,
+src/BrotligDecoder.cpp:437-446, and is undefined beyond that) without faulting the device, leaving the
+next valid decode bit-exact."""
+import numpy as np
+import pytest
+
+from brotli_g_sdk_amd import encoder as E
+from fuzzcases import corrupt, random_plain, random_precon
+from helpers import oracle_decode
+
+pytestmark = pytest.mark.gpu
+
+N_PLAIN = 220
+N_PRECON = 60
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "the gpu tests need a HIP device"
+    from brotli_g_sdk_amd import api as a
+    a.lib()
+    return a
+
+
+@pytest.mark.parametrize("chunk", range(0, N_PLAIN, 44))
+def test_random_streams_batched(api, chunk):
+    """44 random streams per launch (pages of unrelated streams share wavefronts), each compared with the oracle."""
+    datas, streams = [], []
+    for seed in range(chunk, chunk + 44):
+        d, kw = random_plain(seed)
+        datas.append(d)
+        streams.append(E.encode(d, **kw))
+    dec = api.BatchDecoder(streams)
+    dec.poison_output()
+    dec.decode()
+    for i, (d, s) in enumerate(zip(datas, streams)):
+        rc, ref = oracle_decode(s)
+        assert rc == 0 and np.array_equal(ref, d), chunk + i
+        assert np.array_equal(dec.output(i), ref), (chunk + i, random_plain(chunk + i)[1])
+
+
+@pytest.mark.parametrize("seed", range(0, N_PLAIN, 10))
+def test_random_streams_single_asset_entry(api, seed):
+    """The host-pointer entry (DecodeGPU), one stream per call."""
+    d, kw = random_plain(seed)
+    s = E.encode(d, **kw)
+    out, _ = api.DecodeGPU(s)
+    assert np.array_equal(out, d), (seed, kw)
+
+
+def test_random_preconditioned_streams(api):
+    texs, streams = [], []
+    for seed in range(N_PRECON):
+        tex, pre, kw = random_precon(seed)
+        texs.append(tex)
+        streams.append(E.encode(tex, precondition=pre, **kw))
+    dec = api.BatchDecoder(streams, out_sizes=[len(t) for t in texs])
+    dec.poison_output()
+    dec.decode()
+    for i, (t, s) in enumerate(zip(texs, streams)):
+        rc, ref = oracle_decode(s, out_size=len(t))
+        assert rc == 0 and np.array_equal(ref, t), i
+        assert np.array_equal(dec.output(i), ref), (i, random_precon(i)[1])
+
+
+def _valid_reference(api):
+    d, kw = random_plain(3)
+    s = E.encode(d, **kw)
+    return d, s
+
+
+def test_corrupt_streams_return_a_status_and_leave_the_device_usable(api):
+    """120 damaged streams (bit flips, truncation, page-table / page-header / precondition-header damage), decoded
+    alone and in batches next to valid streams.  Any status is acceptable, a fault is not: the valid neighbours
+    in the same launch and a valid decode afterwards must still be bit-exact."""
+    import torch
+    good_d, good_s = _valid_reference(api)
+    n_bad_status = 0
+    for base in range(0, 120, 12):
+        streams, sizes, expect = [], [], []
+        for seed in range(base, base + 12):
+            if seed % 3 == 1:
+                tex, pre, kw = random_precon(seed)
+                s, n = E.encode(tex, precondition=pre, **kw), len(tex)
+            else:
+                d, kw = random_plain(seed)
+                s, n = E.encode(d, **kw), len(d)
+            bad, kind = corrupt(s, seed)
+            if bad[0] != 5 or bad[1] != 250:                        # the two header checks are covered by test_error_codes
+                continue
+            streams.append(bad); sizes.append(n); expect.append(None)
+            streams.append(good_s); sizes.append(len(good_d)); expect.append(good_d)
+        dec = api.BatchDecoder(streams, out_sizes=sizes)
+        dec.poison_output()
+        try:
+            dec.decode()
+        except api.BrotligError as e:
+            assert e.code in (api.BROTLIG_ERROR_CORRUPT_STREAM, api.BROTLIG_ERROR_GENERIC)
+            n_bad_status += 1
+        torch.cuda.synchronize()
+        for i, exp in enumerate(expect):
+            if exp is not None:
+                assert np.array_equal(dec.output(i), exp), (base, i)
+        guard = dec.d_out[dec.out_bytes:].cpu().numpy()
+        assert np.all(guard == 0xCD), "a damaged stream wrote past the output buffer"
+        del dec
+    assert n_bad_status > 0                                         # the damage is noticed at least sometimes
+    out, _ = api.DecodeGPU(good_s)
+    assert np.array_equal(out, good_d)
+
+
+def test_truncated_and_damaged_single_assets(api):
+    """DecodeGPU on damaged single streams: an error code or wrong bytes, never a fault; then a valid decode."""
+    good_d, good_s = _valid_reference(api)
+    for seed in range(200, 240):
+        d, kw = random_plain(seed)
+        s = E.encode(d, **kw)
+        bad, kind = corrupt(s, seed)
+        try:
+            api.DecodeGPU(bad, output_size=len(d))
+        except api.BrotligError as e:
+            assert e.code in (api.BROTLIG_ERROR_CORRUPT_STREAM, api.BROTLIG_ERROR_INCORRECT_STREAM_FORMAT, api.BROTLIG_ERROR_GENERIC)
+    out, _ = api.DecodeGPU(good_s)
+    assert np.array_equal(out, good_d)
+
+
+def test_undersized_output_buffer_is_refused_for_preconditioned_streams(api):
+    """the de-conditioning kernel writes the whole texture; with out_bytes smaller than the texture the
+    stream must be rejected by the prepare kernel (status), and nothing may be written past out_bytes."""
+    import ctypes
+    import torch
+    tex, pre, kw = random_precon(7)
+    tex = np.ascontiguousarray(tex)
+    s = E.encode(tex, precondition=pre, **kw)
+    dec = api.BatchDecoder([s], out_sizes=[len(tex)])
+    dec.poison_output()
+    short = max(16, (dec.out_bytes // 2) & ~15)
+    args = dec._args(dec._stream())
+    args[3] = short                                                  # lie about the output capacity
+    with torch.cuda.device(dec.device):
+        rc = api.lib().BrotligDecodeBatchDevice(*args)
+        assert rc == 0
+        rc = api.lib().BrotligDecodeBatchStatus(dec.d_ws.data_ptr(), dec._stream())
+    assert rc != 0
+    torch.cuda.synchronize()
+    assert bool((dec.d_out[short:] == 0xCD).all())

@@ -1,0 +1,72 @@
+"""BASELINE.json configs[2] and configs[3] at their full 4 GiB on the GPU box, through the same stream builders
+bench.py uses.  Size-independent properties at full size: every tiled repeat of every stream equals the bytes
+that were encoded (compared on the device), a SHA-256 over per-stream SHA-256s of one repeat equals the same
+digest over the source bytes, and stream 0 equals the CPU oracle's output byte for byte."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, oracle_decode
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    import torch
+    assert torch.cuda.is_available(), "the gpu tests need a HIP device"
+    from brotli_g_sdk_amd import api as a
+    a.lib()
+    return a
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _check_batch(api, streams, expected, out_sizes, tiled):
+    import torch
+    dec = api.BatchDecoder(streams, out_sizes=out_sizes)
+    assert dec.decompressed_bytes == 4 * 2**30
+    dec.poison_output()
+    dec.decode()
+    torch.cuda.synchronize()
+    agg_gpu, agg_src = hashlib.sha256(), hashlib.sha256()
+    for k in range(len(streams)):
+        exp = torch.from_numpy(expected[k]).to(dec.device)
+        got = dec.d_out[dec.out_offs[k]:dec.out_offs[k] + dec.sizes[k]].view(-1, exp.numel())
+        assert got.shape[0] == (tiled if tiled else 1)
+        assert bool((got == exp.unsqueeze(0)).all()), k
+        if k < 16:
+            agg_gpu.update(hashlib.sha256(got[-1].cpu().numpy().tobytes()).digest())
+            agg_src.update(hashlib.sha256(expected[k].tobytes()).digest())
+    assert agg_gpu.hexdigest() == agg_src.hexdigest()
+    return dec
+
+
+def test_config3_mixed_4gib_full_size(api):
+    """configs[2] of BASELINE.json (the metric's config): 16 streams x 4096 pages x 64 KiB, mixed synthetic,
+    256 distinct encoded pages per stream tiled 16 times."""
+    B = _bench()
+    streams, expected = B.build_streams("mixed", list(range(16)), 4096, 256)
+    dec = _check_batch(api, streams, expected, None, tiled=16)
+    rc, ref = oracle_decode(streams[0])
+    assert rc == 0 and len(ref) == 256 * 2**20
+    assert np.array_equal(dec.output(0), ref)
+
+
+def test_config4_bc3_4gib_full_size(api):
+    """configs[3]: 256 BC3 textures of 1024 x 1024 blocks (16 MiB, 256 pages each), swizzle + delta; 8 distinct
+    textures repeated as whole streams ("BC7-style" is realised as BC3: the reference has BC1-BC5 only)."""
+    B = _bench()
+    streams, expected = B.build_streams("bc3", list(range(256)), 256, 8)
+    dec = _check_batch(api, streams, expected, [len(e) for e in expected], tiled=0)
+    rc, ref = oracle_decode(streams[0], out_size=len(expected[0]))
+    assert rc == 0
+    assert np.array_equal(dec.output(0), ref)
+    assert np.array_equal(dec.output(255), expected[255])

@@ -6,43 +6,8 @@ import pytest
 
 from brotli_g_sdk_amd import encoder as E
 from helpers import oracle_decode
+from fuzzcases import compose, corrupt, random_plain, random_precon
 from test_sim_decode import run_batch, sim  # noqa: F401  (fixture)
-
-
-def compose(seed, n):
-    rng = np.random.default_rng(seed)
-    out = np.empty(n + 70000, np.uint8)
-    pos = 0
-    while pos < n:
-        kind = rng.integers(0, 8)
-        if kind == 0 or pos < 16:                                   # fresh literals
-            k = int(rng.integers(1, 200))
-            out[pos:pos + k] = rng.integers(0, 256, k, dtype=np.uint8)
-        elif kind == 1:                                             # byte run (distance 1)
-            k = int(rng.integers(2, 3000))
-            out[pos:pos + k] = out[pos - 1]
-        elif kind == 2:                                             # short period, self-overlapping
-            d = int(rng.integers(2, 40)); k = int(rng.integers(d, 2500))
-            for i in range(k):
-                out[pos + i] = out[pos + i - d]
-        elif kind == 3:                                             # near repeat
-            d = int(rng.integers(1, min(pos, 1500)) ) if pos > 1 else 1
-            k = int(rng.integers(2, 64)); k = min(k, d)
-            out[pos:pos + k] = out[pos - d:pos - d + k]
-        elif kind == 4:                                             # far repeat, short
-            d = int(rng.integers(1, pos + 1)); k = int(min(rng.integers(2, 40), d))
-            out[pos:pos + k] = out[pos - d:pos - d + k]
-        elif kind == 5:                                             # far repeat, long
-            d = int(rng.integers(1, pos + 1)); k = int(min(rng.integers(40, 4000), d))
-            out[pos:pos + k] = out[pos - d:pos - d + k]
-        elif kind == 7:                                             # long literal stretch (crosses assembly groups)
-            k = int(rng.integers(500, 5000))
-            out[pos:pos + k] = rng.integers(0, 256, k, dtype=np.uint8)
-        else:                                                       # skewed literals
-            k = int(rng.integers(1, 400))
-            out[pos:pos + k] = np.minimum(rng.geometric(0.3, k) - 1, 255)
-        pos += k
-    return out[:n].copy()
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -73,3 +38,42 @@ def test_sim_corrupt_streams_terminate(sim, seed):
         stream[pos] ^= np.uint8(1 << int(rng.integers(0, 8)))
     outs, status = run_batch(sim, [stream], [len(data)])
     assert len(outs[0]) == len(data)
+
+
+@pytest.mark.parametrize("seed", range(0, 220, 11))
+def test_sim_random_options(sim, seed):
+    """A sample of the on-device differential cases (tests/test_gpu_differential.py) through the simulator."""
+    data, kw = random_plain(seed)
+    stream = E.encode(data, **kw)
+    rc, ref = oracle_decode(stream)
+    assert rc == 0 and np.array_equal(ref, data)
+    outs, status = run_batch(sim, [stream], [len(data)])
+    assert status == 0 and np.array_equal(outs[0], ref)
+
+
+@pytest.mark.parametrize("seed", range(0, 60, 5))
+def test_sim_random_precondition(sim, seed):
+    tex, pre, kw = random_precon(seed)
+    stream = E.encode(tex, precondition=pre, **kw)
+    rc, ref = oracle_decode(stream, out_size=len(tex))
+    assert rc == 0 and np.array_equal(ref, tex)
+    outs, status = run_batch(sim, [stream], [len(tex)], precon=True)
+    assert status == 0 and np.array_equal(outs[0], ref)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_sim_corrupt_variants_stay_in_bounds(sim, seed):
+    """Every corruption kind of fuzzcases.corrupt -- including damaged precondition headers, whose geometry
+    fields drive the de-conditioning kernel's addressing -- terminates and writes nothing outside the output
+    (run_batch checks the guard bytes behind it)."""
+    if seed % 2:
+        tex, pre, kw = random_precon(seed)
+        stream, n, precon = E.encode(tex, precondition=pre, **kw), len(tex), True
+    else:
+        data, kw = random_plain(seed)
+        stream, n, precon = E.encode(data, **kw), len(data), False
+    bad, kind = corrupt(stream, seed)
+    if bad[0] != 5 or bad[1] != 250:
+        return
+    outs, status = run_batch(sim, [bad], [n], precon=precon)
+    assert len(outs[0]) == n
