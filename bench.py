@@ -304,7 +304,6 @@ def main():
     alt = None
     if not args.no_alt_parse and not args.no_cpu_baseline and args.workload not in ("bc3",) and not args.preencoded and world == 1:
         from brotli_g_sdk_amd import encoder as E
-        global ENCODER_FLAGS
         keep = ENCODER_FLAGS
         ENCODER_FLAGS = E.OPTIMAL_PARSE | E.SEARCH_DIST_PARAMS
         t_enc = time.perf_counter()

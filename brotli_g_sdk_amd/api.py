@@ -24,7 +24,8 @@ class BrotligError(RuntimeError):
 
 
 class _StreamDesc(ctypes.Structure):
-    _fields_ = [("in_offset", ctypes.c_uint64), ("out_offset", ctypes.c_uint64)]
+    _fields_ = [("in_offset", ctypes.c_uint64), ("out_offset", ctypes.c_uint64),
+                ("in_size", ctypes.c_uint64), ("out_capacity", ctypes.c_uint64)]
 
 
 _lib = None
@@ -133,9 +134,11 @@ class BatchDecoder:
         host_in = np.zeros(pos + 64, dtype=np.uint8)
         for o, s in zip(in_offs, streams):
             host_in[o:o + len(s)] = s
-        desc = np.zeros((n, 2), dtype=np.uint64)
+        desc = np.zeros((n, 4), dtype=np.uint64)                    # BrotligStreamDesc
         desc[:, 0] = in_offs
         desc[:, 1] = out_offs
+        desc[:, 2] = [len(s) for s in streams]
+        desc[:, 3] = [(out_offs[i + 1] if i + 1 < n else opos) - out_offs[i] for i in range(n)]
         self.d_in = torch.from_numpy(host_in).to(self.device)
         self.d_desc = torch.from_numpy(desc.view(np.int64)).to(self.device)
         self.d_out = torch.empty(opos + 64, dtype=torch.uint8, device=self.device)

@@ -213,7 +213,7 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
     const size_t ws_size = BrotligDecodeWorkspaceSizeFor(1, out_alloc);
     HIP_OK(hipMalloc(&d_ws.p, ws_size));
     HIP_OK(hipMalloc(&d_desc.p, sizeof(BrotligStreamDesc)));
-    const BrotligStreamDesc desc{0, 0};
+    const BrotligStreamDesc desc{0, 0, input_size, *output_size};
     HIP_OK(hipMemset(static_cast<uint8_t*>(d_in.p) + (in_alloc + 64 - 80), 0, 80));
     HIP_OK(hipMemcpy(d_in.p, input, input_size, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_desc.p, &desc, sizeof desc, hipMemcpyHostToDevice));

@@ -33,7 +33,20 @@ namespace brotlig {
 struct StreamDesc {
     uint64_t in_offset;     // byte offset of the stream (its StreamHeader) in the input buffer
     uint64_t out_offset;    // byte offset of its decompressed bytes in the output buffer
+    uint64_t in_size;       // bytes of the stream (0: up to the end of the input buffer)
+    uint64_t out_capacity;  // bytes the stream may write at out_offset (0: up to the end of the output buffer)
 };
+// end of the stream's readable bytes / of its writable region, as offsets into the batch buffers
+__device__ __forceinline__ uint64_t stream_in_end(const StreamDesc& d, uint64_t in_bytes)
+{
+    const uint64_t e = d.in_offset + d.in_size;
+    return (d.in_size != 0u && e < in_bytes) ? e : in_bytes;
+}
+__device__ __forceinline__ uint64_t stream_out_end(const StreamDesc& d, uint64_t out_bytes)
+{
+    const uint64_t e = d.out_offset + d.out_capacity;
+    return (d.out_capacity != 0u && e < out_bytes) ? e : out_bytes;
+}
 
 // Per-stream pre-conditioning parameters, derived once per launch by the prepare kernel from the
 // 8-byte PreconditionHeader (inc/DataStream.h:89-98) the way
@@ -633,14 +646,15 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
         job.page_size = si.page_size;
         job.in = pages + off;
         const uint64_t abs_in = (uint64_t)(job.in - a.in);
-        const uint64_t room = abs_in < a.in_bytes ? a.in_bytes - abs_in : 0;
+        const uint64_t in_end = stream_in_end(a.streams[lo], a.in_bytes);
+        const uint64_t room = abs_in < in_end ? in_end - abs_in : 0;
         job.in_limit = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ((room + 3ull) & ~3ull));
         const uint64_t abs_out = s_out + (uint64_t)i * si.page_size;
         uint8_t* dst_base = si.preconditioned ? a.scratch : a.out;
         job.page_off = i * si.page_size;
         job.dc = si.preconditioned ? &a.dc[lo] : nullptr;
         job.out = dst_base + abs_out;
-        if (abs_out + job.out_size > a.out_bytes || job.in_size > room || dst_base == nullptr) {
+        if (abs_out + job.out_size > stream_out_end(a.streams[lo], a.out_bytes) || job.in_size > room || dst_base == nullptr) {
             job.valid = false;
             atomicOr(a.status, kStatusBadPage);
         }
@@ -1434,18 +1448,26 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
             const uint8_t* p = a.in + a.streams[s].in_offset;
             StreamInfo si;
             const uint64_t in_off = a.streams[s].in_offset;
-            const bool hdr_in = in_off + 8u <= a.in_bytes;
-            if (hdr_in && parse_stream_header(load_u32(p), load_u32(p + 4), si) &&
-                in_off + si.header_bytes + 4ull * si.num_pages <= a.in_bytes) pages = si.num_pages;
+            const uint64_t in_end = stream_in_end(a.streams[s], a.in_bytes), out_end = stream_out_end(a.streams[s], a.out_bytes);
+            const bool hdr_in = in_off + 8u <= in_end;
+            // Beyond the reference's two checks (src/BrotligDecoder.cpp:437-446): the page table must lie inside the
+            // stream, a short last page cannot be longer than a page, and the stream's pages must fit the region the
+            // caller gave it -- a damaged header must not send pages into a neighbouring stream's output.
+            bool ok = hdr_in && parse_stream_header(load_u32(p), load_u32(p + 4), si) &&
+                      in_off + si.header_bytes + 4ull * si.num_pages <= in_end && si.last_page_size <= si.page_size;
+            uint64_t usz = 0;
+            if (ok) {
+                usz = (uint64_t)si.num_pages * si.page_size - (si.last_page_size ? si.page_size - si.last_page_size : 0u);
+                ok = a.streams[s].out_offset + usz <= out_end;
+            }
+            if (ok) pages = si.num_pages;
             else atomicOr(a.status, kStatusBadHeader);
             DcTable& t = a.dc[s];
             t.precon = 0;
             if (pages && si.preconditioned) {
-                // the texture must also lie inside the caller's output buffer: the de-conditioning kernel writes
-                // all of it, whatever happened to the stream's pages
-                const uint64_t usz = uncompressed_size(si);
-                if (in_off + 16u > a.in_bytes || a.scratch == nullptr || a.streams[s].out_offset + usz > a.out_bytes ||
-                    !dc_init(t, load_u32(p + 8), load_u32(p + 12), (uint32_t)usz)) {
+                // the texture described by the precondition header is the stream's output (:478): the de-conditioning
+                // kernel writes all of it, whatever happened to the stream's pages
+                if (a.scratch == nullptr || usz > 0xFFFFFFFFull || !dc_init(t, load_u32(p + 8), load_u32(p + 12), (uint32_t)usz)) {
                     t.precon = 0; pages = 0;                            // the reference has undefined behaviour here
                     atomicOr(a.status, kStatusBadHeader);
                 } else atomicAdd(a.status + 2, 1u);

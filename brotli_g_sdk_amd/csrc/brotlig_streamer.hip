@@ -192,6 +192,8 @@ extern "C" BROTLIG_ERROR BrotligStreamerSubmit(BrotligStreamer* st, uint32_t n, 
         memcpy(s.h_in + in_off[i], inputs[i], input_sizes[i]);
         memset(s.h_in + in_off[i] + input_sizes[i], 0, in_need - input_sizes[i]);
         desc[i].in_offset = in_off[i]; desc[i].out_offset = out_off[i];
+        desc[i].in_size = input_sizes[i];
+        desc[i].out_capacity = (i + 1 < n ? out_off[i + 1] : out_pos) - out_off[i];
         s.user_out[i] = outputs ? outputs[i] : nullptr;
     }
 

@@ -66,6 +66,12 @@ BROTLIG_ERROR DecodeGPU(int useWarpDevice, uint32_t input_size, const uint8_t* i
 typedef struct BrotligStreamDesc {
     uint64_t in_offset;     /* byte offset of the stream's header in d_in; multiple of 4 */
     uint64_t out_offset;    /* byte offset of its decompressed bytes in d_out; multiple of 16 */
+    uint64_t in_size;       /* bytes of the stream, the `input_size` of DecodeCPU / DecodeGPU
+                             * (inc/BrotligDecoder.h:33); 0 = everything up to in_bytes */
+    uint64_t out_capacity;  /* bytes the stream may write at out_offset, the `*output_size` the reference's
+                             * callers pass in (src/BrotligDecoder.cpp:448,:478); 0 = up to out_bytes.
+                             * A stream whose header asks for more is rejected (status), so a damaged
+                             * header cannot reach a neighbouring stream's output. */
 } BrotligStreamDesc;
 
 /* Bytes of device workspace needed for `num_streams` streams (the reference's `meta` buffer). */

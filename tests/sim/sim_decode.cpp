@@ -24,7 +24,11 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
                                 uint32_t num_streams, uint32_t grid, uint32_t* status_out)
 {
     std::vector<StreamDesc> sd(num_streams);
-    for (uint32_t i = 0; i < num_streams; ++i) { sd[i].in_offset = in_offsets[i]; sd[i].out_offset = out_offsets[i]; }
+    for (uint32_t i = 0; i < num_streams; ++i) {
+        sd[i].in_offset = in_offsets[i]; sd[i].out_offset = out_offsets[i];
+        sd[i].in_size = (i + 1 < num_streams ? in_offsets[i + 1] : in_bytes) - in_offsets[i];        // streams lie back to back
+        sd[i].out_capacity = (i + 1 < num_streams ? out_offsets[i + 1] : out_bytes) - out_offsets[i];
+    }
     std::vector<uint32_t> page_base(num_streams + 1, 0);
     uint32_t counter = 0;
     uint32_t status_words[64] = {0};

@@ -131,14 +131,13 @@ def test_truncated_and_damaged_single_assets(api):
 def test_undersized_output_buffer_is_refused_for_preconditioned_streams(api):
     """the de-conditioning kernel writes the whole texture; with out_bytes smaller than the texture the
     stream must be rejected by the prepare kernel (status), and nothing may be written past out_bytes."""
-    import ctypes
     import torch
-    tex, pre, kw = random_precon(7)
-    tex = np.ascontiguousarray(tex)
-    s = E.encode(tex, precondition=pre, **kw)
+    from brotli_g_sdk_amd import datagen as D
+    tex = D.bc_texture(3, 128, 96, seed=11)                                # 192 KiB
+    s = E.encode(tex, precondition=dict(format=3, width_blocks=128, height_blocks=96, swizzle=1, delta=1))
     dec = api.BatchDecoder([s], out_sizes=[len(tex)])
     dec.poison_output()
-    short = max(16, (dec.out_bytes // 2) & ~15)
+    short = len(tex) // 2
     args = dec._args(dec._stream())
     args[3] = short                                                  # lie about the output capacity
     with torch.cuda.device(dec.device):
@@ -148,3 +147,19 @@ def test_undersized_output_buffer_is_refused_for_preconditioned_streams(api):
     assert rc != 0
     torch.cuda.synchronize()
     assert bool((dec.d_out[short:] == 0xCD).all())
+
+
+def test_damaged_header_cannot_reach_a_neighbouring_stream(api):
+    """A stream whose header claims more output than its descriptor's out_capacity (here: LastPageSize with bit 17
+    set, i.e. a "short" last page of 128 KiB + 505 bytes in a 64 KiB page) is rejected as a whole; the stream
+    laid out right behind it decodes bit-exactly."""
+    d = np.frombuffer(bytes(range(256)) * 2, dtype=np.uint8)[:505].copy()
+    s = E.encode(d)
+    bad = s.copy()
+    bad[6] |= 0x08
+    good_d, good_s = _valid_reference(api)
+    dec = api.BatchDecoder([bad, good_s], out_sizes=[len(d), len(good_d)])
+    dec.poison_output()
+    with pytest.raises(api.BrotligError):
+        dec.decode()
+    assert np.array_equal(dec.output(1), good_d)

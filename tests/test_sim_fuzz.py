@@ -77,3 +77,15 @@ def test_sim_corrupt_variants_stay_in_bounds(sim, seed):
         return
     outs, status = run_batch(sim, [bad], [n], precon=precon)
     assert len(outs[0]) == n
+
+
+def test_sim_damaged_header_cannot_reach_a_neighbouring_stream(sim):
+    """LastPageSize with bit 17 set claims a 128 KiB + 505 byte "short" page inside a 64 KiB page: the stream is
+    rejected by the prepare kernel and the stream laid out behind it decodes bit-exactly."""
+    d = np.frombuffer(bytes(range(256)) * 2, dtype=np.uint8)[:505].copy()
+    bad = E.encode(d).copy()
+    bad[6] |= 0x08
+    good, kw = random_plain(3)
+    outs, status = run_batch(sim, [bad, E.encode(good, **kw)], [len(d), len(good)])
+    assert status != 0
+    assert np.array_equal(outs[1], good)
