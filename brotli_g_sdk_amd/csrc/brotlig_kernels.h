@@ -105,7 +105,8 @@ constexpr int kLutBitsDist = 8;
 constexpr int kLutBitsLit = 8;
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
-constexpr uint32_t kShortCopy = 32;         // copies up to this length run one-lane-per-command
+constexpr uint32_t kShortCopy = 32;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
+constexpr uint32_t kOwnCopy = 64;           // copies up to this length run one-lane-per-command (two batches of four chunks)
 // Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
@@ -977,13 +978,21 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             uint64_t fe0 = 0, fe1 = 0, fe2 = 0, fe3 = 0;
             Team ft{5u, 0u, 0u, false};
             uint32_t ft_src = 0, ft_len = 0, ft_stage = 0;
+            // A piece that lies below the window as a whole and does not overlap itself (far_len == plen; at most
+            // kShortCopy bytes on this path) never touches the staging area: its bytes go from these registers
+            // straight to their place in the window once the literals are decoded.  Pieces of 8 bytes and more are
+            // covered by 8-byte chunks at offsets 0, 8, 16, 24 clipped to plen - 8 (the last chunk ends exactly at
+            // the piece's end and overlaps its predecessor); shorter ones by one load and a split store.
+            const bool far_direct = !far_teams && far_len != 0u && far_len == plen;
+            const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
             if (!far_teams) {
                 if (far_len) {
                     const uint8_t* s8 = job.out + psrc;
+                    const uint32_t lim = far_direct ? clip8 : 24u;      // a straddling piece keeps plain offsets (staged)
                     fe0 = load_u64u(s8);
-                    if (far_len > 8u) fe1 = load_u64u(s8 + 8);
-                    if (far_len > 16u) fe2 = load_u64u(s8 + 16);
-                    if (far_len > 24u) fe3 = load_u64u(s8 + 24);
+                    if (far_len > 8u) fe1 = load_u64u(s8 + min_u32(8u, lim));
+                    if (far_len > 16u) fe2 = load_u64u(s8 + min_u32(16u, lim));
+                    if (far_len > 24u) fe3 = load_u64u(s8 + min_u32(24u, lim));
                 }
             } else {
                 ft = make_team(far_mask, sl);
@@ -1098,9 +1107,20 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             }
             clk.lap(kPhLiterals);
 
-            // -- 5a. far sources into the staging area (aligned 8-byte LDS writes)
+            // -- 5a. far sources: short whole pieces straight into the window, everything else into the
+            //        staging area (aligned 8-byte LDS writes)
+            const uint32_t src_idx = psrc - view.win_base;              // window index of the pattern start (negative when far)
+            const uint32_t dst_idx = pdst - view.win_base;
             if (!far_teams) {
-                if (far_len) {
+                if (far_direct) {
+                    uint8_t* d = L.win + dst_idx;
+                    if (plen >= 8u) {
+                        __builtin_memcpy(d, &fe0, 8);
+                        if (plen > 8u) __builtin_memcpy(d + min_u32(8u, clip8), &fe1, 8);
+                        if (plen > 16u) __builtin_memcpy(d + min_u32(16u, clip8), &fe2, 8);
+                        if (plen > 24u) __builtin_memcpy(d + clip8, &fe3, 8);
+                    } else store_bytes(d, fe0, plen);
+                } else if (far_len) {
                     uint64_t* st = &L.stage[stage_off >> 3];
                     st[0] = fe0;
                     if (far_len > 8u) st[1] = fe1;
@@ -1119,49 +1139,92 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             clk.lap(kPhLvLong);
 
             // -- 5b. LZ77 copies in dependency levels.  A piece runs as soon as none of the pieces its
-            //        source overlaps is still unfinished (dep_mask).  Every level shares the 32 lanes among
-            //        its ready pieces (teams of 1..32 lanes), 8 bytes per lane per step; overlapping copies
-            //        replay their pattern modulo the distance, so a copy never waits for itself.  A step's
-            //        reads precede its writes (LDS is in order within the wave).
+            //        source overlaps is still unfinished (dep_mask).  A level without long pieces runs one lane
+            //        per piece; otherwise the ready pieces share the 32 lanes as teams, 8 bytes per lane per step.
+            //        Overlapping copies replay their pattern modulo the distance, so a copy never waits for itself.
             {
                 const uint32_t packed = plen | (far_len << 11) | ((stage_off >> 3) << 22);
-                const uint32_t src_idx = psrc - view.win_base;          // window index of the pattern start (negative when far)
-                const uint32_t dst_idx = pdst - view.win_base;
-                uint32_t todo = wave::half_ballot(plen != 0u);
+                uint32_t todo = wave::half_ballot(plen != 0u && !far_direct);
                 while (wave::any(todo != 0u)) {
                     clk.count(kPhLevels, 1);
                     const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
                     const uint32_t ready_mask = wave::half_ballot(ready);
-                    if (!wave::any(ready && plen > kShortCopy)) {
-                        // no long piece in this level: every ready lane copies its own piece, <= 4 chunks of
-                        // 8 bytes, all loads before the stores
-                        if (ready) {
-                            const uint8_t* own_stage = reinterpret_cast<const uint8_t*>(L.stage) + stage_off;
-                            const uint8_t* own_win = L.win + (int32_t)src_idx;
-                            uint8_t* own_out = L.win + dst_idx;
-                            uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-                            if (far_len == 0u || far_len == pattern) {
-                                const uint8_t* b = far_len ? own_stage : own_win;
-                                uint32_t r = 0;
-                                v0 = pattern_source8(b, dist, r);
-                                if (plen > 8u) { r = advance_mod(r, 8u, dist); v1 = pattern_source8(b, dist, r); }
-                                if (plen > 16u) { r = advance_mod(r, 8u, dist); v2 = pattern_source8(b, dist, r); }
-                                if (plen > 24u) { r = advance_mod(r, 8u, dist); v3 = pattern_source8(b, dist, r); }
-                            } else {                                    // pattern straddles the window boundary
-                                uint32_t rr = 0;
-                                for (uint32_t b = 0; b < 32u && b < plen; ++b) {
-                                    const uint64_t x = rr < far_len ? own_stage[rr] : own_win[rr];
-                                    if (b < 8u) v0 |= x << (8u * b); else if (b < 16u) v1 |= x << (8u * (b - 8u));
-                                    else if (b < 24u) v2 |= x << (8u * (b - 16u)); else v3 |= x << (8u * (b - 24u));
-                                    rr = rr + 1u == dist ? 0u : rr + 1u;
-                                }
+                    if (!wave::any(ready && plen > kOwnCopy)) {
+                        // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
+                        // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
+                        // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
+                        // wrote, and every byte loaded belongs to the source (a piece ready in this level never
+                        // has another ready piece inside its source).
+                        const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(L.stage) + stage_off : L.win + (int32_t)src_idx;
+                        uint8_t* dp = L.win + dst_idx;
+                        const bool whole = far_len == 0u || far_len == pattern;
+                        const bool lane_a = ready && whole && (dist >= 32u || dist >= plen);
+                        const bool lane_b = ready && !lane_a;
+                        if (lane_a) {
+                            if (plen >= 8u) {
+                                const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
+                                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
+                                v0 = load_u64u(sp);
+                                if (plen > 8u) v1 = load_u64u(sp + c1);
+                                if (plen > 16u) v2 = load_u64u(sp + c2);
+                                if (plen > 24u) v3 = load_u64u(sp + c3);
+                                __builtin_memcpy(dp, &v0, 8);
+                                if (plen > 8u) __builtin_memcpy(dp + c1, &v1, 8);
+                                if (plen > 16u) __builtin_memcpy(dp + c2, &v2, 8);
+                                if (plen > 24u) __builtin_memcpy(dp + c3, &v3, 8);
+                            } else {
+                                store_bytes(dp, load_u64u(sp), plen);
                             }
-                            store_bytes(own_out, v0, plen);
-                            if (plen > 8u) store_bytes(own_out + 8, v1, plen - 8u);
-                            if (plen > 16u) store_bytes(own_out + 16, v2, plen - 16u);
-                            if (plen > 24u) store_bytes(own_out + 24, v3, plen - 24u);
+                        }
+                        if (wave::any(lane_a && plen > 32u)) {          // second batch: bytes 32 .. plen - 1 (plen <= kOwnCopy)
+                            if (lane_a && plen > 32u) {
+                                const uint32_t c0 = min_u32(32u, clip8), c1 = min_u32(40u, clip8), c2 = min_u32(48u, clip8);
+                                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
+                                v0 = load_u64u(sp + c0);
+                                if (plen > 40u) v1 = load_u64u(sp + c1);
+                                if (plen > 48u) v2 = load_u64u(sp + c2);
+                                if (plen > 56u) v3 = load_u64u(sp + clip8);
+                                __builtin_memcpy(dp + c0, &v0, 8);
+                                if (plen > 40u) __builtin_memcpy(dp + c1, &v1, 8);
+                                if (plen > 48u) __builtin_memcpy(dp + c2, &v2, 8);
+                                if (plen > 56u) __builtin_memcpy(dp + clip8, &v3, 8);
+                            }
                         }
                         clk.lap(kPhLvShort);
+                        if (wave::any(lane_b)) {
+                            // The rest.  Self-overlapping pieces with a distance below 32 are copied forward in
+                            // 8-byte chunks from `dd` bytes back, each chunk reading what its predecessors wrote
+                            // (LDS accesses of a wave execute in order); a distance below 8 first lays down eight
+                            // bytes of its pattern and then continues from the smallest multiple of itself that is
+                            // >= 8 (8 - dd >= -dist: the read never reaches below the pattern).  Patterns that
+                            // straddle the window boundary go byte by byte.
+                            const uint8_t* own_stage = reinterpret_cast<const uint8_t*>(L.stage) + stage_off;
+                            const uint8_t* own_win = L.win + (int32_t)src_idx;
+                            uint32_t dd = dist, o0 = 0u, r = 0u;
+                            if (lane_b && whole && dist < 8u) {
+                                store_bytes(dp, pattern_source8(sp, dist, 0u), plen);
+                                dd = (uint32_t)(0x0E0C0A0809080800ull >> (8u * dist)) & 0xFFu;     // 8, 8, 9, 8, 10, 12, 14 for 1..7
+                                o0 = 8u;
+                            }
+                            for (uint32_t o = o0; wave::any(lane_b && o < plen); o += 8u) {
+                                if (lane_b && o < plen) {
+                                    uint64_t v;
+                                    if (whole) v = load_u64u(dp + o - dd);
+                                    else {
+                                        v = 0;
+                                        uint32_t rr = r;
+                                        for (uint32_t b = 0; b < 8u; ++b) {
+                                            const uint64_t x = rr < far_len ? own_stage[rr] : own_win[rr];
+                                            v |= x << (8u * b);
+                                            rr = rr + 1u == dist ? 0u : rr + 1u;
+                                        }
+                                        r = advance_mod(r, 8u, dist);
+                                    }
+                                    store_bytes(dp + o, v, plen - o);
+                                }
+                            }
+                            clk.lap(kPhLvBytes);
+                        }
                     } else {
                     const Team t = make_team(ready_mask, sl);
                     const uint32_t t_pk = wave::half_shfl(packed, t.job), t_dist = wave::half_shfl(dist, t.job);
