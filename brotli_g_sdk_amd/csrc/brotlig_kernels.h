@@ -79,7 +79,8 @@ struct DecodeArgs {
 
 // Phase timers (diagnostics build of the kernel only).
 enum : int { kPhSetup, kPhTables, kPhCommands, kPhRing, kPhPositions, kPhLiterals, kPhCopyFence, kPhCopyLevels,
-             kPhDelta, kPhTotal, kPhRounds, kPhLevels, kPhLvShort, kPhLvBytes, kPhLvLong, kPhSlow, kNumPhases };
+             kPhDelta, kPhTotal, kPhRounds, kPhLevels, kPhLvShort, kPhLvBytes, kPhLvLong, kPhSlow,
+             kPhCmdSym, kPhCmdExtra, kPhSlide, kPhPieces, kPhBitmaps, kPhGroups, kPhLitSteps, kPhLvOverlap, kPhTeamLevels, kNumPhases };
 template <bool kOn> struct PhaseClock;
 template <> struct PhaseClock<false> {
     __device__ __forceinline__ void start() {}
@@ -106,7 +107,7 @@ constexpr int kLutBitsLit = 8;
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
 constexpr uint32_t kShortCopy = 32;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
-constexpr uint32_t kOwnCopy = 64;           // copies up to this length run one-lane-per-command (two batches of four chunks)
+constexpr uint32_t kOwnCopy = 128;          // simple copies up to this length run one-lane-per-command (batches of four 8-byte chunks)
 // Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
@@ -768,9 +769,17 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                     if (start) br.init(job.in, job.in_limit, hdr_bytes + incl - my_len);
                 }
                 clk.lap(kPhSetup);
-                build_table(t_icp, L, br, start, sl);
-                build_table(t_dist, L, br, start, sl);
-                build_table(t_lit, L, br, start, sl);
+                // one copy of the table builder in the instruction stream, run three times (ICP, distance, literal):
+                // inlined three times it was most of the kernel's code size, beyond what the instruction cache holds
+#pragma nounroll
+                for (uint32_t k = 0; k < 3u; ++k) {
+                    const TableRef t{k == 0u ? L.lut_icp : k == 1u ? L.lut_dist : L.lut_lit,
+                                     k == 0u ? L.sorted_icp : k == 1u ? L.sorted_dist : L.sorted_lit,
+                                     L.limit[k], L.first_offs[k],
+                                     k == 0u ? kIcpAlphabet : k == 1u ? kDistAlphabet : kLitAlphabet,
+                                     k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit};
+                    build_table(t, L, br, start, sl);
+                }
                 if (start) {
                     ring0 = 4; ring1 = 11; ring2 = 15; ring3 = 16;
                     out_pos = 0; prev_tail = 0; carry_head = 0; flushed = 0; bad = false;
@@ -791,6 +800,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
         //       distance symbol for its extra bits; longer fields (rare) take the general read.
         uint32_t sym = 0, len = 0;
         if (live) { br.ensure(32); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
+        clk.lap(kPhCmdSym);
         const uint32_t sent_mask = wave::half_ballot(live && sym == kSentinel);
         const uint32_t n = sent_mask ? ctz_u32(sent_mask) : 32u;
         const bool is_cmd = live && sl < n;
@@ -813,6 +823,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             } else { xi = br.read(ie); xc = br.read(ce); }
             ins = (it & 0xFFFFu) + xi;
             copy = has_copy ? (ct & 0xFFFFu) + xc : 0u;
+            clk.lap(kPhCmdExtra);
             if (has_copy && sym >= 128u) {                              // explicit distance symbol
                 uint32_t dl;
                 br.ensure(32);
@@ -950,6 +961,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                 view.win_base = nb;
             }
             wave::sync();
+            clk.lap(kPhSlide);
+            clk.count(kPhGroups, 1);
             const uint32_t span0 = gpos - view.win_base;                // window index of the group's first byte
 
             // -- 3c. my pieces in this group
@@ -1002,6 +1015,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                 if (ft.serves && 8u * ft.member < ft_len) fe0 = load_u64u(job.out + ft_src + 8u * ft.member);
                 if (ft.serves && 8u * (ft.member + (1u << ft.log2_size)) < ft_len) fe1 = load_u64u(job.out + ft_src + 8u * (ft.member + (1u << ft.log2_size)));
             }
+            clk.lap(kPhPieces);
             // literals of the group: consumption indices [F0, F1)
             const uint32_t mine_before = (on && ok_cmd) ? (cs <= g0 ? ins : (rel0 < g0 ? g0 - rel0 : 0u)) : 0u;   // my literals before g0
             uint32_t F0 = 0, F1 = litcount;                             // single group: all of the round's literals
@@ -1033,6 +1047,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                 if (on && sl < kRoundMax / 32u) { L.start_cum[sl] = (uint8_t)(cw - (uint32_t)__popc(w)); L.lit_cum[sl] = (uint8_t)(cv - (uint32_t)__popc(v)); }
             }
             wave::sync();
+            clk.lap(kPhBitmaps);
             // exact dependencies of my copy piece: the pieces (of commands before me) that own bytes of my
             // source range inside this group; everything below the group is final
             uint32_t dep_mask = 0;
@@ -1088,6 +1103,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                 // two literals per refill check while at least two are left (a literal is at most 15 bits)
                 for (; next_j + 32u < J1; next_j += 64u) {
                     uint32_t l0, l1;
+                    clk.count(kPhLitSteps, 1);
                     br.ensure(30);
                     const uint32_t lit0 = decode_symbol<kLutBitsLit>(t_lit, br, l0);
                     br.consume(l0);
@@ -1144,12 +1160,15 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             //        Overlapping copies replay their pattern modulo the distance, so a copy never waits for itself.
             {
                 const uint32_t packed = plen | (far_len << 11) | ((stage_off >> 3) << 22);
+                // simple piece: pattern in one place (window or staging area) and no chunk of a 32-byte batch reads
+                // what an earlier chunk of the batch wrote
+                const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
                 uint32_t todo = wave::half_ballot(plen != 0u && !far_direct);
                 while (wave::any(todo != 0u)) {
                     clk.count(kPhLevels, 1);
                     const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
                     const uint32_t ready_mask = wave::half_ballot(ready);
-                    if (!wave::any(ready && plen > kOwnCopy)) {
+                    if (!wave::any(ready && plen > (simple ? kOwnCopy : kShortCopy))) {
                         // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
                         // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
                         // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
@@ -1158,8 +1177,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                         const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(L.stage) + stage_off : L.win + (int32_t)src_idx;
                         uint8_t* dp = L.win + dst_idx;
                         const bool whole = far_len == 0u || far_len == pattern;
-                        const bool lane_a = ready && whole && (dist >= 32u || dist >= plen);
-                        const bool lane_b = ready && !lane_a;
+                        const bool lane_a = ready && simple;
+                        const bool lane_b = ready && !simple;
                         if (lane_a) {
                             if (plen >= 8u) {
                                 const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
@@ -1176,18 +1195,18 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                                 store_bytes(dp, load_u64u(sp), plen);
                             }
                         }
-                        if (wave::any(lane_a && plen > 32u)) {          // second batch: bytes 32 .. plen - 1 (plen <= kOwnCopy)
-                            if (lane_a && plen > 32u) {
-                                const uint32_t c0 = min_u32(32u, clip8), c1 = min_u32(40u, clip8), c2 = min_u32(48u, clip8);
+                        for (uint32_t o = 32u; wave::any(lane_a && plen > o); o += 32u) {      // further batches: bytes o .. min(o + 32, plen) - 1
+                            if (lane_a && plen > o) {
+                                const uint32_t c0 = min_u32(o, clip8), c1 = min_u32(o + 8u, clip8), c2 = min_u32(o + 16u, clip8), c3 = min_u32(o + 24u, clip8);
                                 uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
                                 v0 = load_u64u(sp + c0);
-                                if (plen > 40u) v1 = load_u64u(sp + c1);
-                                if (plen > 48u) v2 = load_u64u(sp + c2);
-                                if (plen > 56u) v3 = load_u64u(sp + clip8);
+                                if (plen > o + 8u) v1 = load_u64u(sp + c1);
+                                if (plen > o + 16u) v2 = load_u64u(sp + c2);
+                                if (plen > o + 24u) v3 = load_u64u(sp + c3);
                                 __builtin_memcpy(dp + c0, &v0, 8);
-                                if (plen > 40u) __builtin_memcpy(dp + c1, &v1, 8);
-                                if (plen > 48u) __builtin_memcpy(dp + c2, &v2, 8);
-                                if (plen > 56u) __builtin_memcpy(dp + clip8, &v3, 8);
+                                if (plen > o + 8u) __builtin_memcpy(dp + c1, &v1, 8);
+                                if (plen > o + 16u) __builtin_memcpy(dp + c2, &v2, 8);
+                                if (plen > o + 24u) __builtin_memcpy(dp + c3, &v3, 8);
                             }
                         }
                         clk.lap(kPhLvShort);
@@ -1223,9 +1242,10 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                                     store_bytes(dp + o, v, plen - o);
                                 }
                             }
-                            clk.lap(kPhLvBytes);
+                            clk.lap(kPhLvOverlap);
                         }
                     } else {
+                    clk.count(kPhTeamLevels, 1);
                     const Team t = make_team(ready_mask, sl);
                     const uint32_t t_pk = wave::half_shfl(packed, t.job), t_dist = wave::half_shfl(dist, t.job);
                     const uint32_t t_src = wave::half_shfl(src_idx, t.job), t_dst = wave::half_shfl(dst_idx, t.job);

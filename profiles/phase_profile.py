@@ -11,7 +11,7 @@ dec = api.BatchDecoder(streams)
 dec.decode()
 p = dec.phase_profile()
 tot = p["total"]
-out = {k: (v if k in ("rounds", "levels", "solo_rounds") else round(v / tot, 4)) for k, v in p.items()}
+out = {k: (v if k in ("rounds", "levels", "solo_rounds", "groups", "lit_steps", "team_levels") else round(v / tot, 4)) for k, v in p.items()}
 out["levels_per_round"] = round(p["levels"] / max(p["rounds"], 1), 2)
 out["cycles_per_round"] = round(tot / max(p["rounds"], 1), 1)
 out["pages"] = int(sum(api.DecompressedSize(s) for s in streams) // 65536)

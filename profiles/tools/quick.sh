@@ -1,6 +1,6 @@
 #!/bin/bash
-# Quick perf check on the MI355X box: python bench lines for the main workloads + the phase profile.
-#   bash profiles/tools/quick.sh <tag> [workloads...]
+# Quick perf check on the MI355X box: bench lines for the given workloads + the phase profile.
+#   bash profiles/tools/quick.sh <tag> [workloads...]      (PROFILE="mixed text" chooses the phase profiles)
 tag=${1:-quick}; shift
 wl=${@:-"mixed text runs bc3 samples16 records"}
 out=gpurun_out/$tag; mkdir -p $out
@@ -14,5 +14,5 @@ for l in sys.stdin:
         d = json.loads(l); print('$w', d['value'], 'GB/s  kernel_ms', d['roofline']['kernel_ms'], 'exact', d['bit_exact'])
 " | tee -a $out/summary.txt
 done
-for k in "mixed 16" "text 16"; do python profiles/phase_profile.py $k; done > $out/phase_profile.jsonl 2>>$out/err.log
+for k in ${PROFILE:-mixed}; do python profiles/phase_profile.py $k 16; done > $out/phase_profile.jsonl 2>>$out/err.log
 cat $out/phase_profile.jsonl
