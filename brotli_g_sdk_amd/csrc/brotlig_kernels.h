@@ -166,6 +166,7 @@ static_assert(sizeof(uint16_t) * ((1 << kLutBitsDist) + (1 << kLutBitsLit)) >= k
 static_assert(sizeof(uint16_t) * (1 << kLutBitsLit) + kStageBytes >= kTableScratchBytes, "literal build scratch");
 static_assert(__builtin_offsetof(PageLds, lut_dist) == sizeof(uint16_t) * (1 << kLutBitsIcp), "LUTs must be contiguous");
 static_assert(__builtin_offsetof(PageLds, stage) == sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)), "staging area must follow the LUTs");
+static_assert(kHist + 16u <= 1024u && kWin <= 1024u, "the slide moves at most two 16-byte pieces per lane");
 static_assert(kWin + 48 >= kIcpAlphabet, "the window holds the code lengths during the table build");
 
 struct __attribute__((aligned(16))) WaveLds {
@@ -174,6 +175,10 @@ struct __attribute__((aligned(16))) WaveLds {
 };
 
 __device__ __forceinline__ uint64_t load_u64u_g(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+// sixteen bytes at a 16-byte aligned address, kept in registers (one b128 access)
+typedef uint32_t Bytes16 __attribute__((vector_size(16)));
+__device__ __forceinline__ Bytes16 load16(const uint8_t* p) { return *reinterpret_cast<const Bytes16*>(__builtin_assume_aligned(p, 16)); }
+__device__ __forceinline__ void store16(uint8_t* p, Bytes16 v) { *reinterpret_cast<Bytes16*>(__builtin_assume_aligned(p, 16)) = v; }
 
 // ---- per-lane bit reader over one sub-bitstream ---------------------------------------------
 // LSB-first.  `buf` holds `avail` valid bits.  Behind it sit 64 queued bits (`queue`, `queued` of them
@@ -943,21 +948,28 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             // -- 3b. make room in the window: flush finished bytes (aligned 16-byte stores), then slide,
             //        keeping kHist >= kWin / 2 bytes of history: every byte flushed by THIS slide is still
             //        inside the window, so reads from global memory only touch bytes flushed by an earlier
-            //        slide.  The move runs 256 bytes per step, all reads of a step before its writes; the
-            //        destination trails the source, so no unread byte is overwritten.
+            //        slide.  `flushed` is 16-byte aligned until the page's last flush and at most kWin bytes lie
+            //        between it and the group, so the flush is two 16-byte pieces per lane; the move brings the
+            //        kHist .. kHist + 15 bytes of history down in one step, all reads before the writes.
             const bool slide = on && out_pos + g1 > view.win_base + kWin;
             wave::sync();
             if (wave::any(slide)) {
-                if (slide) flushed = flush_window(job.out, view, flushed, gpos, false, sl);
+                if (slide) {
+                    const uint32_t e16 = gpos & ~15u;
+                    const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
+                    if (p0 < e16) store16(job.out + p0, load16(view.win + (p0 - view.win_base)));
+                    if (p1 < e16) store16(job.out + p1, load16(view.win + (p1 - view.win_base)));
+                    if (e16 > flushed) flushed = e16;
+                }
                 const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
                 const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
-                for (uint32_t i0 = 0; wave::any(i0 < count); i0 += 256u) {
-                    const uint32_t i = i0 + 8u * sl;
-                    const uint64_t v = i < count ? load_u64u(view.win + shift + i) : 0ull;
-                    wave::sync();
-                    if (i < count) __builtin_memcpy(view.win + i, &v, 8);
-                    wave::sync();
-                }
+                const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
+                Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = {0u, 0u, 0u, 0u};
+                if (i0 < count) m0 = load16(view.win + shift + i0);
+                if (i1 < count) m1 = load16(view.win + shift + i1);
+                wave::sync();
+                if (i0 < count) store16(view.win + i0, m0);
+                if (i1 < count) store16(view.win + i1, m1);
                 view.win_base = nb;
             }
             wave::sync();
