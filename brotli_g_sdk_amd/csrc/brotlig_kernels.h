@@ -100,6 +100,16 @@ template <> struct PhaseClock<true> {
     }
 };
 
+// Ablation switches for profiling builds (profiles/tools/ablate.sh): parts of the LZ77 assembly are skipped --
+// the output is wrong, the entropy decode and its control flow are unchanged -- to see what each part costs.
+// The product is built without BROTLIG_ABLATE (mask 0: every `if` below folds away).
+#ifndef BROTLIG_ABLATE
+#define BROTLIG_ABLATE 0
+#endif
+enum : uint32_t { kAblLevels = 1u, kAblTeams = 2u, kAblOverlap = 4u, kAblFar = 8u, kAblSlide = 16u, kAblDeps = 32u, kAblLitStore = 64u,
+                  kAblOwnLane = 128u };
+constexpr uint32_t kAblate = BROTLIG_ABLATE;
+
 // ---- tunables ---------------------------------------------------------------------------
 constexpr int kLutBitsIcp = 8;
 constexpr int kLutBitsDist = 8;
@@ -185,39 +195,33 @@ __device__ __forceinline__ void store16(uint8_t* p, Bytes16 v) { *reinterpret_ca
 // still unread) and 64 bits in flight from global memory (`flight`): a refill takes 32 queued bits,
 // and only every second refill touches the in-flight pair -- loaded at least two refills earlier --
 // and issues the next 8-byte load.  Loads are 8 bytes at 4-byte aligned offsets.
+// Bounds: the input allocation extends 16 bytes past in_bytes (include/brotlig_amd.h), so no load a valid
+// stream needs is ever cut short; a reader that has run away on a corrupt stream is held at the last 8
+// readable bytes (`limit8`) and decodes whatever is there (the reference over-reads unchecked,
+// inc/common/BrotligDeswizzler.h:74-81).
 struct BitReader {
     const uint8_t* base;    // page start in the input buffer
-    uint32_t limit;         // bytes readable from base (reads beyond return 0)
+    uint32_t limit8;        // last byte offset from base at which 8 bytes may be loaded
     uint64_t buf;
     uint32_t avail;
     uint32_t next;          // byte offset of the next 8-byte load, dword aligned relative to base
     uint64_t queue;
     uint32_t queued;        // 0, 32 or 64
-    uint64_t flight;        // raw 8 bytes as loaded; `flight_sh` says how to turn them into the wanted ones
-    uint32_t flight_sh;
+    uint64_t flight;        // the 8 bytes loaded last, not waited for until they are needed
+    uint32_t zero;          // wave::opaque_zero()
 
-    // Issues the 8-byte load for byte offset `rel` without touching its result: near the end of the
-    // readable input the load is moved back to the last 8 readable bytes (always inside the input
-    // buffer: at least 12 bytes of headers precede every page) and `sh` is the right shift that
-    // aligns it (>= 64: nothing readable at `rel`).  Branch-free on purpose: a conditional load
-    // would reach `flight` through a register copy, and the copy would wait for the load just issued.
-    __device__ __forceinline__ uint64_t load8_raw(uint32_t rel, uint32_t& sh) const
-    {
-        const bool inside = rel + 8u <= limit;
-        const int32_t a = inside ? (int32_t)rel : (int32_t)limit - 8;
-        sh = inside ? 0u : (rel - (uint32_t)a) * 8u;
-        return load_u64u_g(base + a);
-    }
-    static __device__ __forceinline__ uint64_t settle(uint64_t raw, uint32_t sh) { return sh >= 64u ? 0ull : raw >> sh; }
+    // Issues the 8-byte load for byte offset `rel` without touching its result.  Branch-free on purpose: a
+    // conditional load would reach `flight` through a register copy, and the copy would wait for the load
+    // just issued.
+    __device__ __forceinline__ uint64_t load8(uint32_t rel) const { return load_u64u_g(base + min_rel(rel)); }
+    __device__ __forceinline__ uint32_t min_rel(uint32_t rel) const { return rel < limit8 ? rel : limit8; }
     __device__ __forceinline__ void init(const uint8_t* b, uint32_t lim, uint32_t start)
     {
-        base = b; limit = lim;
+        base = b; limit8 = lim >= 8u ? lim - 8u : 0u; zero = wave::opaque_zero();
         const uint32_t a = start & ~3u, skip = (start & 3u) * 8u;
-        uint32_t sh0;
-        const uint64_t raw0 = load8_raw(a, sh0);
+        const uint64_t first = load8(a);
         next = a + 8u;
-        flight = load8_raw(next, flight_sh); next += 8u;
-        const uint64_t first = settle(raw0, sh0);
+        flight = load8(next); next += 8u;
         buf = (uint64_t)((uint32_t)first >> skip);
         avail = 32u - skip;
         queue = first >> 32; queued = 32u;
@@ -225,7 +229,9 @@ struct BitReader {
     }
     __device__ __forceinline__ void refill()
     {
-        if (queued == 0u) { queue = settle(flight, flight_sh); queued = 64u; flight = load8_raw(next, flight_sh); next += 8u; }
+        // `flight >> zero` rather than a copy: with a plain copy the compiler keeps the old pair where it is, loads
+        // the new one into a scratch pair and copies it over -- and that copy waits for the load just issued
+        if (queued == 0u) { queue = flight >> zero; queued = 64u; flight = load8(next); next += 8u; }
         buf |= (uint64_t)(uint32_t)queue << avail;
         queue >>= 32; queued -= 32u;
         avail += 32u;
@@ -633,16 +639,20 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
 {
     PageJob job;
     job.valid = ok;
-    job.in = a.in; job.out = a.out; job.in_size = job.out_size = 0; job.in_limit = 0; job.page_size = kMinPageSize;
+    job.in = nullptr; job.out = nullptr; job.in_size = job.out_size = 0; job.in_limit = 0; job.page_size = kMinPageSize;
     job.page_off = 0; job.dc = nullptr;
     if (job.valid) {
         if (order != nullptr) g = order[g];                             // the schedule built by the order kernels
+        const uint32_t* const page_base = a.page_base;
+        const StreamDesc* const streams = a.streams;
+        const uint8_t* const in = a.in;
+        const uint64_t in_bytes = a.in_bytes, out_bytes = a.out_bytes;
         // stream lookup: largest s with page_base[s] <= g
         uint32_t lo = 0, hi = a.num_streams;
-        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (a.page_base[mid] <= g) lo = mid; else hi = mid; }
-        const uint32_t i = g - a.page_base[lo];
-        const uint64_t s_in = a.streams[lo].in_offset, s_out = a.streams[lo].out_offset;
-        const uint8_t* sp = a.in + s_in;
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (page_base[mid] <= g) lo = mid; else hi = mid; }
+        const uint32_t i = g - page_base[lo];
+        const uint64_t s_in = streams[lo].in_offset, s_out = streams[lo].out_offset;
+        const uint8_t* sp = in + s_in;
         StreamInfo si;
         parse_stream_header(load_u32(sp), load_u32(sp + 4), si);
         const uint8_t* table = sp + si.header_bytes;
@@ -652,16 +662,19 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
         job.out_size = (i + 1u == si.num_pages && si.last_page_size) ? si.last_page_size : si.page_size;  // :314
         job.page_size = si.page_size;
         job.in = pages + off;
-        const uint64_t abs_in = (uint64_t)(job.in - a.in);
-        const uint64_t in_end = stream_in_end(a.streams[lo], a.in_bytes);
+        const uint64_t abs_in = (uint64_t)(job.in - in);
+        const uint64_t in_end = stream_in_end(streams[lo], in_bytes);
         const uint64_t room = abs_in < in_end ? in_end - abs_in : 0;
-        job.in_limit = (uint32_t)(room > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ((room + 3ull) & ~3ull));
+        // bytes readable from the page start: up to the end of the input buffer plus its 16 bytes of padding
+        // (reads may run into the next stream: harmless, a valid page never consumes those bits)
+        const uint64_t readable = abs_in < in_bytes ? in_bytes - abs_in + 16ull : 0ull;
+        job.in_limit = (uint32_t)(readable > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : readable);
         const uint64_t abs_out = s_out + (uint64_t)i * si.page_size;
         uint8_t* dst_base = si.preconditioned ? a.scratch : a.out;
         job.page_off = i * si.page_size;
-        job.dc = si.preconditioned ? &a.dc[lo] : nullptr;
+        job.dc = si.preconditioned ? a.dc + lo : nullptr;
         job.out = dst_base + abs_out;
-        if (abs_out + job.out_size > stream_out_end(a.streams[lo], a.out_bytes) || job.in_size > room || dst_base == nullptr) {
+        if (abs_out + job.out_size > stream_out_end(streams[lo], out_bytes) || job.in_size > room || dst_base == nullptr) {
             job.valid = false;
             atomicOr(a.status, kStatusBadPage);
         }
@@ -684,24 +697,21 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
     const uint32_t lane = wave::lane_id();
     const uint32_t sl = lane & 31u;
     PageLds& L = W.page[lane >> 5];
-    uint32_t* const status = a.status;
-    const uint32_t total = a.page_base[a.num_streams];
-    const uint32_t resync_quarters = a.status[3];                       // pairing policy, set by the prepare kernel
 
     // the three prefix codes of a page: ICP, distance, literal (PageDecoder.cpp:125-147)
     const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first_offs[0], kIcpAlphabet, kLutBitsIcp};
     const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist};
     const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit};
 
+    const uint32_t resync_quarters = a.status[3];                       // pairing policy, set by the prepare kernel
     // ---- per-half state of the page under construction
-    const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
-    PageJob job = fetch_job(a, order, 0u, false);
+    PageJob job = fetch_job(a, nullptr, 0u, false);
     bool live = false;               // inside a compressed page
     bool finished = false;           // the work counter ran out for this half
     uint32_t npostfix = 0, ndirect = 0;
     bool is_delta = false;
     BitReader br;
-    br.base = a.in; br.limit = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.flight_sh = 64;
+    br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
     uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16;             // PageDecoder.cpp:150-153
     uint32_t out_pos = 0;            // bytes of the page produced so far
     uint32_t prev_tail = 0;          // literals decoded but not yet consumed
@@ -724,13 +734,16 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             const bool want = !live && !finished && other_near == 0u;
             if (wave::any(want)) {
                 clk.lap(kPhDelta);
+                const uint32_t total = a.page_base[a.num_streams];
+                const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
+                uint32_t* const work_counter = a.work_counter;
                 // Stored pages (PageDecoder.cpp:70-76) are copied on the spot and rejected ones skipped: a
                 // half keeps taking pages until it holds a compressed one, so that both halves reach the
                 // table build together.
                 bool need = want, start = false;
                 while (wave::any(need)) {
                     uint32_t g = 0;
-                    if (need && sl == 0u) g = atomicAdd(a.work_counter, 1u);
+                    if (need && sl == 0u) g = atomicAdd(work_counter, 1u);
                     g = wave::half_bcast(g, 0u);
                     const bool got = need && g < total;
                     if (need && !got) { finished = true; need = false; }
@@ -951,22 +964,24 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             //        slide.  `flushed` is 16-byte aligned until the page's last flush and at most kWin bytes lie
             //        between it and the group, so the flush is two 16-byte pieces per lane; the move brings the
             //        kHist .. kHist + 15 bytes of history down in one step, all reads before the writes.
-            const bool slide = on && out_pos + g1 > view.win_base + kWin;
+            const bool slide = on && out_pos + g1 > view.win_base + kWin && !(kAblate & kAblSlide);
             wave::sync();
             if (wave::any(slide)) {
-                if (slide) {
-                    const uint32_t e16 = gpos & ~15u;
-                    const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
-                    if (p0 < e16) store16(job.out + p0, load16(view.win + (p0 - view.win_base)));
-                    if (p1 < e16) store16(job.out + p1, load16(view.win + (p1 - view.win_base)));
-                    if (e16 > flushed) flushed = e16;
-                }
+                // all four LDS reads first (two for the flush, two for the move), then the stores
+                const uint32_t e16 = gpos & ~15u;
+                const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
+                const bool f0 = slide && p0 < e16, f1 = slide && p1 < e16;
                 const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
                 const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
                 const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
-                Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = {0u, 0u, 0u, 0u};
+                Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0, m0 = a0, m1 = a0;
+                if (f0) a0 = load16(view.win + (p0 - view.win_base));
+                if (f1) a1 = load16(view.win + (p1 - view.win_base));
                 if (i0 < count) m0 = load16(view.win + shift + i0);
                 if (i1 < count) m1 = load16(view.win + shift + i1);
+                if (f0) store16(job.out + p0, a0);
+                if (f1) store16(job.out + p1, a1);
+                if (slide && e16 > flushed) flushed = e16;
                 wave::sync();
                 if (i0 < count) store16(view.win + i0, m0);
                 if (i1 < count) store16(view.win + i1, m1);
@@ -991,7 +1006,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             const uint32_t src_end = psrc + pattern;
             // the first far_len bytes of the pattern lie below the window: fetched from global memory
             // into the staging area (loads issued now, consumed after the literal decode)
-            const uint32_t far_len = (plen && psrc < view.win_base) ? min_u32(pattern, view.win_base - psrc) : 0u;
+            const uint32_t far_len = (plen && psrc < view.win_base && !(kAblate & kAblFar)) ? min_u32(pattern, view.win_base - psrc) : 0u;
             const uint32_t stage_len = (far_len + 7u) & ~7u;
             const uint32_t stage_incl = wave::half_scan_incl(stage_len);
             const uint32_t stage_off = stage_incl - stage_len;          // 8-byte aligned offset into L.stage
@@ -1063,7 +1078,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             // exact dependencies of my copy piece: the pieces (of commands before me) that own bytes of my
             // source range inside this group; everything below the group is final
             uint32_t dep_mask = 0;
-            if (plen && src_end > gpos) {
+            if (plen && src_end > gpos && !(kAblate & kAblDeps)) {
                 const uint32_t hi_rel = src_end - 1u - gpos;
                 const uint32_t hi = L.start_cum[hi_rel >> 5] + (uint32_t)__popc(L.start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
                 uint32_t lo = 0;
@@ -1107,7 +1122,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                             const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
                             shift = L.lit_shift[run & 31u];
                         }
-                        L.win[span0 - g0 + f + shift] = (uint8_t)lit;
+                        if (!(kAblate & kAblLitStore)) L.win[span0 - g0 + f + shift] = (uint8_t)lit;
                     } else {
                         L.carry[(keep_at + (f - litcount)) & 63u] = (uint8_t)lit;
                     }
@@ -1175,12 +1190,12 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                 // simple piece: pattern in one place (window or staging area) and no chunk of a 32-byte batch reads
                 // what an earlier chunk of the batch wrote
                 const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
-                uint32_t todo = wave::half_ballot(plen != 0u && !far_direct);
+                uint32_t todo = wave::half_ballot(plen != 0u && !far_direct && !(kAblate & kAblLevels));
                 while (wave::any(todo != 0u)) {
                     clk.count(kPhLevels, 1);
                     const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
                     const uint32_t ready_mask = wave::half_ballot(ready);
-                    if (!wave::any(ready && plen > (simple ? kOwnCopy : kShortCopy))) {
+                    if ((kAblate & kAblTeams) || !wave::any(ready && plen > (simple ? kOwnCopy : kShortCopy))) {
                         // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
                         // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
                         // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
@@ -1189,8 +1204,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                         const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(L.stage) + stage_off : L.win + (int32_t)src_idx;
                         uint8_t* dp = L.win + dst_idx;
                         const bool whole = far_len == 0u || far_len == pattern;
-                        const bool lane_a = ready && simple;
-                        const bool lane_b = ready && !simple;
+                        const bool lane_a = ready && simple && !(kAblate & kAblOwnLane);
+                        const bool lane_b = ready && !simple && !(kAblate & kAblOverlap);
                         if (lane_a) {
                             if (plen >= 8u) {
                                 const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
@@ -1361,7 +1376,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             }
         }
     }
-    if (ended && bad && sl == 0u) atomicOr(status, kStatusBadPage);
+    if (ended && bad && sl == 0u) atomicOr(a.status, kStatusBadPage);
     }
     clk.lap(kPhDelta);
     clk.flush(a.prof, lane);

@@ -53,6 +53,15 @@ __device__ __forceinline__ uint32_t half_bcast(uint32_t v, uint32_t src)
     return lane_id() < 32u ? a : b;
 }
 
+// Zero, in a scalar register, that the compiler cannot see through.  Used to turn a register-to-register
+// copy into an ALU operation (x >> opaque_zero()) where a copy would be placed badly -- see BitReader::refill.
+__device__ __forceinline__ uint32_t opaque_zero()
+{
+    uint32_t z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+}
+
 // A value the caller knows to be the same in every lane, moved to a scalar register.
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 

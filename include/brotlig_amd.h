@@ -82,8 +82,10 @@ size_t BrotligDecodeWorkspaceSize(uint32_t num_streams);
 size_t BrotligDecodeWorkspaceSizeFor(uint32_t num_streams, uint64_t out_bytes);
 
 /* Enqueue the decode of `num_streams` streams.
- *   d_in / in_bytes       device buffer holding the streams; must stay readable 8 bytes past
- *                         in_bytes only in the sense that reads beyond in_bytes are suppressed
+ *   d_in / in_bytes       device buffer holding the streams; the allocation must extend 16 bytes past
+ *                         in_bytes (contents irrelevant: the bit readers prefetch ahead, like the
+ *                         reference's 8-byte over-read, inc/common/BrotligDeswizzler.h:74-81, and a
+ *                         valid stream never consumes those bits).  d_in itself 16-byte aligned.
  *   d_out / out_bytes     device buffer receiving the decompressed bytes; the allocation must
  *                         extend 8 bytes past out_bytes (wide source reads of the last page;
  *                         nothing is written there).  Same for d_scratch.

@@ -25,6 +25,7 @@ inline uint32_t bcast(uint32_t v, uint32_t src, SIM_SITE)
     return (uint32_t)sim::g_wave.in_a[s][src & 63u];
 }
 inline uint32_t uniform(uint32_t v) { return v; }
+inline uint32_t opaque_zero() { return 0u; }
 inline uint32_t other_half(uint32_t v, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);
