@@ -107,7 +107,7 @@ template <> struct PhaseClock<true> {
 #define BROTLIG_ABLATE 0
 #endif
 enum : uint32_t { kAblLevels = 1u, kAblTeams = 2u, kAblOverlap = 4u, kAblFar = 8u, kAblSlide = 16u, kAblDeps = 32u, kAblLitStore = 64u,
-                  kAblOwnLane = 128u };
+                  kAblOwnLane = 128u, kExpNoB = 256u };
 constexpr uint32_t kAblate = BROTLIG_ABLATE;
 
 // ---- tunables ---------------------------------------------------------------------------
@@ -323,6 +323,15 @@ __device__ __forceinline__ uint32_t mod_u16(uint32_t j, uint32_t d)
     if (rem < 0) rem += (int32_t)d;
     if ((uint32_t)rem >= d) rem -= (int32_t)d;
     return (uint32_t)rem;
+}
+// j / d for j < 2^22, 1 <= d <= 64: reciprocal estimate plus one correction either way.
+__device__ __forceinline__ uint32_t div_small(uint32_t j, uint32_t d)
+{
+    uint32_t q = (uint32_t)((float)j * __builtin_amdgcn_rcpf((float)d));
+    const int32_t rem = (int32_t)(j - q * d);
+    if (rem < 0) --q;
+    if (rem >= (int32_t)d) ++q;
+    return q;
 }
 // Teams: `count` jobs share the 32 lanes of a half; each job gets 32 >> ceil_log2(count) lanes.
 struct Team { uint32_t log2_size; uint32_t job; uint32_t member; bool serves; };
@@ -939,7 +948,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
         const uint32_t lit_a = incl_ins - ins;                          // my literals are consumption indices [lit_a, lit_a + ins)
         const uint32_t rel0 = incl_tot - tot;                           // my first byte, relative to the round
         const uint32_t ac = litcount > prev_tail ? litcount - prev_tail : 0u;
-        const uint32_t mult = (live && n) ? (ac + n - 1u) / n : 0u;
+        const uint32_t mult = (live && n) ? div_small(min_u32(ac, 0x200000u) + n - 1u, n) : 0u;
         const uint32_t rlit = n * mult;                                 // literals decoded this round (0 when !live)
         uint32_t next_j = sl;                                           // next literal of the round this lane decodes
         const bool dist_ok = dist != 0u && dist <= copy_dst;
@@ -1195,7 +1204,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                     clk.count(kPhLevels, 1);
                     const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
                     const uint32_t ready_mask = wave::half_ballot(ready);
-                    if ((kAblate & kAblTeams) || !wave::any(ready && plen > (simple ? kOwnCopy : kShortCopy))) {
+                    if ((kAblate & kAblTeams) || !wave::any(ready && (plen > (simple ? kOwnCopy : kShortCopy) || ((kAblate & kExpNoB) && !simple)))) {
                         // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
                         // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
                         // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
@@ -1205,7 +1214,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                         uint8_t* dp = L.win + dst_idx;
                         const bool whole = far_len == 0u || far_len == pattern;
                         const bool lane_a = ready && simple && !(kAblate & kAblOwnLane);
-                        const bool lane_b = ready && !simple && !(kAblate & kAblOverlap);
+                        const bool lane_b = ready && !simple && !(kAblate & (kAblOverlap | kExpNoB));
                         if (lane_a) {
                             if (plen >= 8u) {
                                 const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
