@@ -53,6 +53,20 @@ __device__ __forceinline__ uint32_t half_bcast(uint32_t v, uint32_t src)
     return lane_id() < 32u ? a : b;
 }
 
+// Hand-over between the wavefronts of one workgroup through LDS (one CU, one LDS: accesses are performed in
+// the order the LDS unit receives them).  A producer writes its data, then publishes a counter with
+// lds_store_release; a consumer polls the counter with lds_load_acquire and then reads the data.
+__device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// Give the SIMD to the other wavefronts for a moment (inside a polling loop).
+__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(2); }
+
 // Zero, in a scalar register, that the compiler cannot see through.  Used to turn a register-to-register
 // copy into an ALU operation (x >> opaque_zero()) where a copy would be placed badly -- see BitReader::refill.
 __device__ __forceinline__ uint32_t opaque_zero()

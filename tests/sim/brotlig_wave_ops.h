@@ -15,27 +15,30 @@ inline uint64_t ballot64(bool p, SIM_SITE)
 {
     const int s = sim::collective_enter(p ? 1 : 0, 0, site);
     uint64_t m = 0;
-    for (int l = 0; l < sim::kLanes; ++l) if (!sim::g_wave.fiber[l].done && sim::g_wave.in_a[s][l]) m |= 1ull << l;
+    for (int l = 0; l < sim::kLanes; ++l) if (!sim::cw().fiber[l].done && sim::cw().in_a[s][l]) m |= 1ull << l;
     return m;
 }
 inline bool any(bool p, SIM_SITE) { return ballot64(p, site) != 0; }
 inline uint32_t bcast(uint32_t v, uint32_t src, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);
-    return (uint32_t)sim::g_wave.in_a[s][src & 63u];
+    return (uint32_t)sim::cw().in_a[s][src & 63u];
 }
 inline uint32_t uniform(uint32_t v) { return v; }
 inline uint32_t opaque_zero() { return 0u; }
+inline uint32_t lds_load_acquire(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+inline void lds_store_release(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+inline void nap() { sim::yield_to_scheduler(); }      // let the other wave of the workgroup run
 inline uint32_t other_half(uint32_t v, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);
-    return (uint32_t)sim::g_wave.in_a[s][lane_id() < 32u ? 32 : 0];
+    return (uint32_t)sim::cw().in_a[s][lane_id() < 32u ? 32 : 0];
 }
 inline uint32_t half_ballot(bool p, SIM_SITE) { return (uint32_t)(ballot64(p, site) >> (lane_id() & 32u)); }
 inline uint32_t half_shfl(uint32_t v, uint32_t src, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);
-    return (uint32_t)sim::g_wave.in_a[s][(lane_id() & 32u) | (src & 31u)];
+    return (uint32_t)sim::cw().in_a[s][(lane_id() & 32u) | (src & 31u)];
 }
 inline uint32_t half_bcast(uint32_t v, uint32_t src, SIM_SITE)
 {
@@ -43,17 +46,17 @@ inline uint32_t half_bcast(uint32_t v, uint32_t src, SIM_SITE)
     const int s = sim::collective_enter(v, src, site);
     const uint32_t base = lane_id() & 32u;
     for (uint32_t l = base; l < base + 32u; ++l)
-        if (!sim::g_wave.fiber[l].done && sim::g_wave.in_b[s][l] != src) {
+        if (!sim::cw().fiber[l].done && sim::cw().in_b[s][l] != src) {
             fprintf(stderr, "SIM: half_bcast with a non-uniform source lane at line %d\n", site); abort();
         }
-    return (uint32_t)sim::g_wave.in_a[s][base | (src & 31u)];
+    return (uint32_t)sim::cw().in_a[s][base | (src & 31u)];
 }
 inline uint32_t half_scan_incl(uint32_t v, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);
     const uint32_t me = lane_id(), base = me & 32u;
     uint32_t acc = 0;
-    for (uint32_t l = base; l <= me; ++l) acc += (uint32_t)sim::g_wave.in_a[s][l];
+    for (uint32_t l = base; l <= me; ++l) acc += (uint32_t)sim::cw().in_a[s][l];
     return acc;
 }
 inline uint32_t half_scan_incl_ref(uint32_t v, SIM_SITE) { return half_scan_incl(v, site); }
@@ -62,7 +65,7 @@ inline uint32_t half_sum(uint32_t v, SIM_SITE)
     const int s = sim::collective_enter(v, 0, site);
     const uint32_t base = lane_id() & 32u;
     uint32_t acc = 0;
-    for (uint32_t l = base; l < base + 32u; ++l) acc += (uint32_t)sim::g_wave.in_a[s][l];
+    for (uint32_t l = base; l < base + 32u; ++l) acc += (uint32_t)sim::cw().in_a[s][l];
     return acc;
 }
 inline uint32_t half_max(uint32_t v, SIM_SITE)
@@ -70,7 +73,7 @@ inline uint32_t half_max(uint32_t v, SIM_SITE)
     const int s = sim::collective_enter(v, 0, site);
     const uint32_t base = lane_id() & 32u;
     uint32_t acc = 0;
-    for (uint32_t l = base; l < base + 32u; ++l) { const uint32_t x = (uint32_t)sim::g_wave.in_a[s][l]; acc = x > acc ? x : acc; }
+    for (uint32_t l = base; l < base + 32u; ++l) { const uint32_t x = (uint32_t)sim::cw().in_a[s][l]; acc = x > acc ? x : acc; }
     return acc;
 }
 inline void sync(SIM_SITE) { sim::collective_enter(0, 0, site); }
@@ -79,4 +82,4 @@ inline void global_fence(SIM_SITE) { sim::collective_enter(0, 0, site); }
 #undef SIM_SITE
 }  // namespace wave
 
-inline void __syncthreads() { wave::sync(); }
+inline void __syncthreads(int site = __builtin_LINE()) { sim::barrier_enter(site); }

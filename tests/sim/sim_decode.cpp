@@ -52,7 +52,7 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
 extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word 3: pairing policy chosen by the prepare kernel
 extern "C" void sim_set_order(int on) { g_use_order = on; }
 extern "C" void sim_selftest(uint32_t* out) { sim::run_grid(1, selftest_body, out); }
-extern "C" uint64_t sim_collectives() { return sim::g_wave.n_collectives; }
+extern "C" uint64_t sim_collectives() { return sim::g_waves[0].n_collectives; }
 
 // The kernels' own view of the two headers, for the constant checks of tests/test_reference_kats.py.
 extern "C" int sim_dc_table(uint32_t w0, uint32_t w1, uint32_t out_size, uint32_t* words /* sizeof(DcTable) / 4 */)

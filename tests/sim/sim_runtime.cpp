@@ -7,7 +7,9 @@
 
 namespace sim {
 
-WaveState g_wave;
+WaveState g_waves[kMaxWaves];
+WaveState* g_cw = &g_waves[0];
+uint64_t g_barrier_gen = 0;
 
 // Minimal context switch: callee-saved registers + stack pointer.
 asm(R"(
@@ -35,9 +37,11 @@ sim_switch:
 
 static void fiber_entry()
 {
-    WaveState& w = g_wave;
-    w.body(w.arg);
-    w.fiber[w.cur].done = true;
+    {
+        WaveState& w = cw();
+        w.body(w.arg);
+    }
+    cw().fiber[cw().cur].done = true;
     for (;;) yield_to_scheduler();
 }
 
@@ -47,59 +51,89 @@ constexpr size_t kStackBytes = 512 * 1024;
 static void on_segv(int)
 {
     char msg[128];
-    int n = snprintf(msg, sizeof msg, "SIM: SIGSEGV in lane %d (block %u), last cross-lane site line %d\n",
-                     g_wave.cur, g_wave.block, g_wave.site[g_wave.cur]);
+    int n = snprintf(msg, sizeof msg, "SIM: SIGSEGV in wave %d lane %d (block %u), last cross-lane site line %d\n",
+                     cw().index, cw().cur, cw().block, cw().site[cw().cur]);
     (void)!write(2, msg, (size_t)n);
     void* bt[32];
     backtrace_symbols_fd(bt, backtrace(bt, 32), 2);
     _exit(139);
 }
 
-void run_grid(uint32_t grid, void (*body)(void*), void* arg)
+void run_grid(uint32_t grid, void (*body)(void*), void* arg, int waves)
 {
-    WaveState& w = g_wave;
     static bool hooked = false;
     if (!hooked) { hooked = true; static char alt[65536]; stack_t ss{alt, 0, sizeof alt}; sigaltstack(&ss, nullptr);
         struct sigaction sa{}; sa.sa_handler = on_segv; sa.sa_flags = SA_ONSTACK; sigaction(SIGSEGV, &sa, nullptr); }
-    w.grid = grid; w.body = body; w.arg = arg;
-    static void* stacks[kLanes] = {nullptr};
-    for (int l = 0; l < kLanes; ++l) if (!stacks[l]) stacks[l] = aligned_alloc(64, kStackBytes);
+    if (waves < 1 || waves > kMaxWaves) { fprintf(stderr, "SIM: %d waves per workgroup not supported\n", waves); abort(); }
+    static void* stacks[kMaxWaves][kLanes] = {{nullptr}};
+    for (int v = 0; v < waves; ++v)
+        for (int l = 0; l < kLanes; ++l) if (!stacks[v][l]) stacks[v][l] = aligned_alloc(64, kStackBytes);
     for (uint32_t b = 0; b < grid; ++b) {
-        w.block = b; w.gen = 0;
-        for (int l = 0; l < kLanes; ++l) {
-            Fiber& f = w.fiber[l];
-            f.stack = stacks[l]; f.done = false; w.waiting[l] = false;
-            uintptr_t top = ((uintptr_t)stacks[l] + kStackBytes) & ~(uintptr_t)15;
-            void** sp = (void**)top;
-            *--sp = nullptr;                    // fake return address of fiber_entry
-            *--sp = (void*)&fiber_entry;        // popped by `ret`
-            for (int r = 0; r < 6; ++r) *--sp = nullptr;
-            f.sp = sp;
+        for (int v = 0; v < waves; ++v) {
+            WaveState& w = g_waves[v];
+            w.grid = grid; w.body = body; w.arg = arg; w.block = b; w.gen = 0; w.index = v;
+            for (int l = 0; l < kLanes; ++l) {
+                Fiber& f = w.fiber[l];
+                f.stack = stacks[v][l]; f.done = false; w.waiting[l] = false; w.at_barrier[l] = false;
+                uintptr_t top = ((uintptr_t)stacks[v][l] + kStackBytes) & ~(uintptr_t)15;
+                void** sp = (void**)top;
+                *--sp = nullptr;                    // fake return address of fiber_entry
+                *--sp = (void*)&fiber_entry;        // popped by `ret`
+                for (int r = 0; r < 6; ++r) *--sp = nullptr;
+                f.sp = sp;
+            }
         }
         for (;;) {
-            int live = 0, waiting = 0;
-            for (int l = 0; l < kLanes; ++l) {
-                if (w.fiber[l].done) continue;
-                if (!w.waiting[l]) { w.cur = l; sim_switch(&w.sched_sp, w.fiber[l].sp); }
-                if (!w.fiber[l].done) { ++live; if (w.waiting[l]) ++waiting; }
-            }
-            if (live == 0) break;
-            if (waiting != live) continue;      // some lane still runnable (cannot happen: lanes run to a wait)
-            // every live lane is parked in a collective: they must agree on the call site
-            int site = -1;
-            for (int l = 0; l < kLanes; ++l) {
-                if (w.fiber[l].done) continue;
-                if (site < 0) site = w.site[l];
-                else if (site != w.site[l]) {
-                    fprintf(stderr, "SIM: divergent cross-lane op: lane %d at line %d, earlier lanes at line %d (block %u)\n",
-                            l, w.site[l], site, b);
-                    abort();
+            int live_total = 0, at_barrier_total = 0;
+            bool progress = false;
+            for (int v = 0; v < waves; ++v) {
+                WaveState& w = g_waves[v];
+                g_cw = &w;
+                int live = 0, waiting = 0, barrier = 0;
+                for (int l = 0; l < kLanes; ++l) {
+                    if (w.fiber[l].done) continue;
+                    if (!w.waiting[l] && !w.at_barrier[l]) { w.cur = l; sim_switch(&w.sched_sp, w.fiber[l].sp); progress = true; }
+                    if (!w.fiber[l].done) { ++live; if (w.waiting[l]) ++waiting; if (w.at_barrier[l]) ++barrier; }
                 }
+                live_total += live; at_barrier_total += barrier;
+                if (live == 0 || waiting == 0) continue;
+                if (waiting != live) {
+                    if (waiting + barrier == live) {
+                        fprintf(stderr, "SIM: wave %d: %d lanes in a cross-lane op while %d lanes wait at a workgroup barrier (block %u)\n",
+                                v, waiting, barrier, b);
+                        abort();
+                    }
+                    continue;
+                }
+                // every live lane of this wave is parked in a collective: they must agree on the call site
+                int site = -1;
+                for (int l = 0; l < kLanes; ++l) {
+                    if (w.fiber[l].done) continue;
+                    if (site < 0) site = w.site[l];
+                    else if (site != w.site[l]) {
+                        fprintf(stderr, "SIM: divergent cross-lane op: wave %d lane %d at line %d, earlier lanes at line %d (block %u)\n",
+                                v, l, w.site[l], site, b);
+                        abort();
+                    }
+                }
+                for (int l = 0; l < kLanes; ++l) w.waiting[l] = false;
+                ++w.gen; ++w.n_collectives;
+                progress = true;
             }
-            for (int l = 0; l < kLanes; ++l) w.waiting[l] = false;
-            ++w.gen; ++w.n_collectives;
+            if (live_total == 0) break;
+            if (at_barrier_total == live_total) {                       // the whole workgroup has arrived
+                for (int v = 0; v < waves; ++v) for (int l = 0; l < kLanes; ++l) g_waves[v].at_barrier[l] = false;
+                ++g_barrier_gen;
+                progress = true;
+            }
+            if (!progress) {
+                fprintf(stderr, "SIM: deadlock in block %u: %d live lanes, %d at the workgroup barrier, the rest gone or stuck\n",
+                        b, live_total, at_barrier_total);
+                abort();
+            }
         }
     }
+    g_cw = &g_waves[0];
 }
 
 }  // namespace sim

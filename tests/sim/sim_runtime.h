@@ -1,8 +1,9 @@
 // sim_runtime.h -- TEST INFRASTRUCTURE: a tiny CPU stand-in for the HIP execution model so the
 // kernel source in brotli_g_sdk_amd/csrc/brotlig_kernels.h can be executed and debugged on a box
-// without a GPU.  One workgroup (= one wave64) runs at a time; each lane is a fiber; every
-// cross-lane primitive in tests/sim/brotlig_wave_ops.h is a rendezvous of all live lanes that also
-// checks that every lane arrived from the same call site (the kernel's wave-uniformity rule).
+// without a GPU.  One workgroup (one or more wave64s) runs at a time; each lane is a fiber; every
+// cross-lane primitive in tests/sim/brotlig_wave_ops.h is a rendezvous of all live lanes of the wave that also
+// checks that every lane arrived from the same call site (the kernel's wave-uniformity rule);
+// __syncthreads() is a rendezvous of all live lanes of all waves of the workgroup.
 // Nothing here is part of the product, and the product never includes this file.
 #pragma once
 #include <stdint.h>
@@ -43,14 +44,21 @@ struct WaveState {
     uint64_t in_a[2][kLanes], in_b[2][kLanes];
     int      site[kLanes];
     bool     waiting[kLanes];
+    bool     at_barrier[kLanes];  // parked in __syncthreads()
     uint64_t n_collectives;
+    int      index;               // wave number inside the workgroup
 };
 
-extern WaveState g_wave;
+constexpr int kMaxWaves = 4;
+extern WaveState g_waves[kMaxWaves];
+extern WaveState* g_cw;           // the wave whose fiber is running
+extern uint64_t g_barrier_gen;    // completed workgroup barriers
+inline WaveState& cw() { return *g_cw; }
+#define g_wave cw()
 
 extern "C" void sim_switch(void** from_sp, void* to_sp);
 
-inline void yield_to_scheduler() { sim_switch(&g_wave.fiber[g_wave.cur].sp, g_wave.sched_sp); }
+inline void yield_to_scheduler() { WaveState& w = cw(); sim_switch(&w.fiber[w.cur].sp, w.sched_sp); }
 
 // Deposit operands, wait until every live lane has done so, return the parity slot to read.
 inline int collective_enter(uint64_t a, uint64_t b, int site)
@@ -65,16 +73,27 @@ inline int collective_enter(uint64_t a, uint64_t b, int site)
     return slot;
 }
 
-void run_grid(uint32_t grid, void (*body)(void*), void* arg);
+// Park the running fiber until every live lane of every wave of the workgroup has arrived.
+inline void barrier_enter(int site)
+{
+    WaveState& w = cw();
+    const int lane = w.cur;
+    const uint64_t my_gen = g_barrier_gen;
+    w.site[lane] = site; w.at_barrier[lane] = true;
+    while (g_barrier_gen == my_gen) yield_to_scheduler();
+}
 
-inline uint32_t lane_now() { return (uint32_t)g_wave.cur; }
+void run_grid(uint32_t grid, void (*body)(void*), void* arg, int waves = 1);
+
+inline uint32_t lane_now() { return (uint32_t)cw().cur; }
+inline uint32_t thread_now() { return (uint32_t)(cw().index * kLanes + cw().cur); }
 
 }  // namespace sim
 
 // ---- HIP built-ins used by the kernels --------------------------------------------------------
-struct SimThreadIdx { uint32_t y = 0, z = 0; struct X { operator uint32_t() const { return sim::lane_now(); } } x; };
-struct SimBlockIdx { uint32_t y = 0, z = 0; struct X { operator uint32_t() const { return sim::g_wave.block; } } x; };
-struct SimGridDim { uint32_t y = 1, z = 1; struct X { operator uint32_t() const { return sim::g_wave.grid; } } x; };
+struct SimThreadIdx { uint32_t y = 0, z = 0; struct X { operator uint32_t() const { return sim::thread_now(); } } x; };
+struct SimBlockIdx { uint32_t y = 0, z = 0; struct X { operator uint32_t() const { return sim::cw().block; } } x; };
+struct SimGridDim { uint32_t y = 1, z = 1; struct X { operator uint32_t() const { return sim::cw().grid; } } x; };
 struct SimBlockDim { uint32_t y = 1, z = 1; uint32_t x = sim::kLanes; };
 static const SimBlockDim blockDim;
 static const SimThreadIdx threadIdx;
