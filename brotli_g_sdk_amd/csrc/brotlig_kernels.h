@@ -126,6 +126,7 @@ constexpr uint32_t kWin = 1024;
 constexpr uint32_t kHist = 512;             // history kept across a slide (>= kWin / 2: see the slide below)
 constexpr uint32_t kRoundMax = kWin - kHist;
 constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
+static_assert(kStageBytes >= kRoundMax + 64u, "the staging area also holds a group's literals, with slack for 8-byte reads");
 
 // insert / copy length codes: base | extra_bits << 16   (RFC 7932 section 5; the reference carries
 // them as sBrotligCmdLut, inc/common/BrotligCommandLut.h:41-747, and the shader regenerates them
@@ -154,19 +155,17 @@ struct __attribute__((aligned(16))) PageLds {
     uint16_t lut_icp[1 << kLutBitsIcp];
     uint16_t lut_dist[1 << kLutBitsDist];
     uint16_t lut_lit[1 << kLutBitsLit];
-    uint64_t stage[kStageBytes / 8];        // per group: source bytes of far copies (older than the window)
+    uint64_t stage[kStageBytes / 8];        // per group: first the group's literals in consumption order (they move to
+                                            // the window before the far sources arrive), then the source bytes of far
+                                            // copies (older than the window)
     uint32_t sorted_icp[(kIcpAlphabet + 2) / 3];       // symbols in canonical-code order, three 10-bit fields per word
     uint32_t sorted_dist[(kDistAlphabet + 2) / 3];
     uint32_t sorted_lit[kLitAlphabet / 4];             // literals fit a byte each: plain byte array
     uint16_t limit[3][16] __attribute__((aligned(16)));     // per code length: exclusive upper bound, left-justified to 15 bits
     uint32_t first_offs[3][16]; // per code length: first code (left-justified) | index of its first symbol in sorted_* << 16
     uint32_t start_bits[kRoundMax / 32];    // per group: bit p set <=> a command's piece starts at group byte p
-    uint32_t lit_bits[kRoundMax / 32];      // per group: bit i set <=> the group's i-th literal starts a literal run
-    uint32_t lit_shift[32];                 // per group: (round-relative position - consumption index) of the r-th run
     uint8_t  start_cum[kRoundMax / 32];     // per group: piece starts in earlier words of start_bits
-    uint8_t  lit_cum[kRoundMax / 32];       // per group: run starts in earlier words of lit_bits
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
-    uint8_t  sink[64];              // write target of inactive lanes in branch-free copy loops
     uint8_t  win[kWin + 48] __attribute__((aligned(16)));   // output window; doubles as the code-length
                                                              // scratch (728 B) while tables are built
 };
@@ -323,6 +322,43 @@ __device__ __forceinline__ uint32_t mod_u16(uint32_t j, uint32_t d)
     if (rem < 0) rem += (int32_t)d;
     if ((uint32_t)rem >= d) rem -= (int32_t)d;
     return (uint32_t)rem;
+}
+// Copy of `len` bytes by the lane itself when no chunk of a 32-byte batch reads what an earlier chunk of the batch
+// wrote (no overlap, or distance >= 32): 8-byte chunks at offsets clipped to len - 8 (the last chunk ends at the
+// piece's end and overlaps its predecessor), the loads of a batch before its stores.
+__device__ __forceinline__ void own_copy_simple(const uint8_t* sp, uint8_t* dp, uint32_t len, bool on)
+{
+    const uint32_t clip8 = len >= 8u ? len - 8u : 0u;
+    if (on) {
+        if (len >= 8u) {
+            const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
+            uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
+            v0 = load_u64u(sp);
+            if (len > 8u) v1 = load_u64u(sp + c1);
+            if (len > 16u) v2 = load_u64u(sp + c2);
+            if (len > 24u) v3 = load_u64u(sp + c3);
+            __builtin_memcpy(dp, &v0, 8);
+            if (len > 8u) __builtin_memcpy(dp + c1, &v1, 8);
+            if (len > 16u) __builtin_memcpy(dp + c2, &v2, 8);
+            if (len > 24u) __builtin_memcpy(dp + c3, &v3, 8);
+        } else {
+            store_bytes(dp, load_u64u(sp), len);
+        }
+    }
+    for (uint32_t o = 32u; wave::any(on && len > o); o += 32u) {
+        if (on && len > o) {
+            const uint32_t c0 = min_u32(o, clip8), c1 = min_u32(o + 8u, clip8), c2 = min_u32(o + 16u, clip8), c3 = min_u32(o + 24u, clip8);
+            uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
+            v0 = load_u64u(sp + c0);
+            if (len > o + 8u) v1 = load_u64u(sp + c1);
+            if (len > o + 16u) v2 = load_u64u(sp + c2);
+            if (len > o + 24u) v3 = load_u64u(sp + c3);
+            __builtin_memcpy(dp + c0, &v0, 8);
+            if (len > o + 8u) __builtin_memcpy(dp + c1, &v1, 8);
+            if (len > o + 16u) __builtin_memcpy(dp + c2, &v2, 8);
+            if (len > o + 24u) __builtin_memcpy(dp + c3, &v3, 8);
+        }
+    }
 }
 // j / d for j < 2^22, 1 <= d <= 64: reciprocal estimate plus one correction either way.
 __device__ __forceinline__ uint32_t div_small(uint32_t j, uint32_t d)
@@ -1056,31 +1092,19 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             const uint32_t mine_before = (on && ok_cmd) ? (cs <= g0 ? ins : (rel0 < g0 ? g0 - rel0 : 0u)) : 0u;   // my literals before g0
             uint32_t F0 = 0, F1 = litcount;                             // single group: all of the round's literals
             if (multi_group) { F0 = wave::half_sum(mine_before); F1 = F0 + wave::half_sum(nlit); }
-            const uint32_t run_mask = wave::half_ballot(nlit != 0u);
             const uint32_t piece_mask = wave::half_ballot(in_group);
-            // one literal run in the group (long inserts): its shift is all a literal needs
-            const bool one_run = (run_mask & (run_mask - 1u)) == 0u;
-            const uint32_t shift1 = wave::half_bcast(rel0 - lit_a, run_mask ? ctz_u32(run_mask) : 0u);
-            if (on && sl < kRoundMax / 32u) {
-                L.start_bits[sl] = 0u;
-                L.lit_bits[sl] = 0u;
-            }
+            if (on && sl < kRoundMax / 32u) L.start_bits[sl] = 0u;
             wave::sync();
             if (in_group) {
                 const uint32_t b = (rel0 > g0 ? rel0 : g0) - g0;        // my first byte in the group
                 atomicOr(&L.start_bits[b >> 5], 1u << (b & 31u));
-                if (nlit) {
-                    const uint32_t j0 = lit_f - F0;
-                    atomicOr(&L.lit_bits[j0 >> 5], 1u << (j0 & 31u));
-                    L.lit_shift[__popc(run_mask & ((1u << sl) - 1u))] = rel0 - lit_a;     // position - consumption index
-                }
             }
             wave::sync();
             {
                 const bool rd = on && sl < kRoundMax / 32u;
-                const uint32_t w = rd ? L.start_bits[sl] : 0u, v = rd ? L.lit_bits[sl] : 0u;
-                const uint32_t cw = wave::half_scan_incl((uint32_t)__popc(w)), cv = wave::half_scan_incl((uint32_t)__popc(v));
-                if (on && sl < kRoundMax / 32u) { L.start_cum[sl] = (uint8_t)(cw - (uint32_t)__popc(w)); L.lit_cum[sl] = (uint8_t)(cv - (uint32_t)__popc(v)); }
+                const uint32_t w = rd ? L.start_bits[sl] : 0u;
+                const uint32_t cw = wave::half_scan_incl((uint32_t)__popc(w));
+                if (rd) L.start_cum[sl] = (uint8_t)(cw - (uint32_t)__popc(w));
             }
             wave::sync();
             clk.lap(kPhBitmaps);
@@ -1106,35 +1130,23 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
 
             // -- 4. literals of the group.  Literal j of the round comes from sub-stream j mod 32 and is
             //       consumption index prev_tail + j (PageDecoder.cpp:196-206); indices below prev_tail were
-            //       decoded in earlier rounds and wait in the carry ring.  Each literal goes straight to its
-            //       place: the owning literal run is the number of run starts at or below it (bitmap +
-            //       popcount), and a run's literals sit at consumption index + a per-run shift.
+            //       decoded in earlier rounds and wait in the carry ring.  They are laid down in consumption
+            //       order (the reference's literal queue, PageDecoder.cpp:164-166,:209-211, one group at a time), in
+            //       the staging area, which is free until the far sources are stored; then every command moves its
+            //       own run to the window like a short copy.
+            uint8_t* const lits = reinterpret_cast<uint8_t*>(L.stage);
             if (on) {
-                const uint32_t cf0 = F0, cf1 = F1 < prev_tail ? F1 : prev_tail;        // carried part of [F0, F1)
-                for (uint32_t f = cf0 + sl; f < cf1; f += 32u) {
-                    const uint32_t idx = f - F0;
-                    const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
-                    L.win[span0 - g0 + f + L.lit_shift[run & 31u]] = L.carry[(carry_head + f) & 63u];
-                }
+                const uint32_t cf1 = F1 < prev_tail ? F1 : prev_tail;                   // carried part of [F0, F1)
+                for (uint32_t f = F0 + sl; f < cf1; f += 32u) lits[f - F0] = L.carry[(carry_head + f) & 63u];
                 // the last group also decodes the literals beyond what the round consumes (fewer than 32):
                 // they wait in the carry ring for the next round
                 const bool last_group = g + 1u == ngroups;
                 const uint32_t J1 = last_group ? rlit : (F1 > prev_tail ? F1 - prev_tail : 0u);
                 const uint32_t keep_at = carry_head + prev_tail;        // ring index of consumption index `litcount` (mod 64)
-                // where literal number j of the round goes
                 auto place = [&](uint32_t j, uint32_t lit) {
                     const uint32_t f = prev_tail + j;
-                    if (f < litcount) {
-                        uint32_t shift = shift1;
-                        if (!one_run) {
-                            const uint32_t idx = f - F0;
-                            const uint32_t run = L.lit_cum[idx >> 5] + (uint32_t)__popc(L.lit_bits[idx >> 5] & (0xFFFFFFFFu >> (31u - (idx & 31u)))) - 1u;
-                            shift = L.lit_shift[run & 31u];
-                        }
-                        if (!(kAblate & kAblLitStore)) L.win[span0 - g0 + f + shift] = (uint8_t)lit;
-                    } else {
-                        L.carry[(keep_at + (f - litcount)) & 63u] = (uint8_t)lit;
-                    }
+                    if (f < litcount) lits[f - F0] = (uint8_t)lit;
+                    else L.carry[(keep_at + (f - litcount)) & 63u] = (uint8_t)lit;
                 };
                 // two literals per refill check while at least two are left (a literal is at most 15 bits)
                 for (; next_j + 32u < J1; next_j += 64u) {
@@ -1157,6 +1169,24 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                     next_j += 32u;
                 }
             }
+            wave::sync();
+            // -- 4b. literal runs: from the queue to their place in the window (own lane; long inserts in teams)
+            if (!(kAblate & kAblLitStore)) {
+                const uint32_t q_idx = lit_f - F0, w_idx = span0 - g0 + la;
+                own_copy_simple(lits + q_idx, L.win + w_idx, nlit, nlit != 0u && nlit <= kOwnCopy);
+                if (wave::any(nlit > kOwnCopy)) {
+                    const uint32_t lmask = wave::half_ballot(nlit > kOwnCopy);
+                    const Team tl = make_team(lmask, sl);
+                    const uint32_t l_src = wave::half_shfl(q_idx, tl.job), l_dst = wave::half_shfl(w_idx, tl.job);
+                    const uint32_t l_len = wave::half_shfl(nlit, tl.job);
+                    const bool act = tl.serves && lmask != 0u;
+                    for (uint32_t c = tl.member; wave::any(act && 8u * c < l_len); c += 1u << tl.log2_size) {
+                        const uint32_t j = 8u * c;
+                        if (act && j < l_len) store_bytes(L.win + l_dst + j, load_u64u(lits + l_src + j), l_len - j);
+                    }
+                }
+            }
+            wave::sync();
             clk.lap(kPhLiterals);
 
             // -- 5a. far sources: short whole pieces straight into the window, everything else into the
