@@ -122,9 +122,10 @@ constexpr uint32_t kOwnCopy = 128;          // simple copies up to this length r
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
 // flushed to global memory in aligned 16-byte stores when it slides.
-constexpr uint32_t kWin = 1024;
-constexpr uint32_t kHist = 512;             // history kept across a slide (>= kWin / 2: see the slide below)
-constexpr uint32_t kRoundMax = kWin - kHist;
+constexpr uint32_t kWin = 1536;
+constexpr uint32_t kHist = 528;             // history kept across a slide (>= kRoundMax + 16: see the slide below)
+constexpr uint32_t kRoundMax = 512;          // bytes assembled per group
+static_assert(kHist >= kRoundMax + 16u && kWin >= kHist + 16u + kRoundMax, "window: history + one group");
 constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
 static_assert(kStageBytes >= kRoundMax + 64u, "the staging area also holds a group's literals, with slack for 8-byte reads");
 
@@ -175,7 +176,7 @@ static_assert(sizeof(uint16_t) * ((1 << kLutBitsDist) + (1 << kLutBitsLit)) >= k
 static_assert(sizeof(uint16_t) * (1 << kLutBitsLit) + kStageBytes >= kTableScratchBytes, "literal build scratch");
 static_assert(__builtin_offsetof(PageLds, lut_dist) == sizeof(uint16_t) * (1 << kLutBitsIcp), "LUTs must be contiguous");
 static_assert(__builtin_offsetof(PageLds, stage) == sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)), "staging area must follow the LUTs");
-static_assert(kHist + 16u <= 1024u && kWin <= 1024u, "the slide moves at most two 16-byte pieces per lane");
+static_assert(kHist + 16u <= 1024u && kWin - kHist >= 512u + 16u, "the slide moves at most two 16-byte pieces per lane; a group fits behind the history");
 static_assert(kWin + 48 >= kIcpAlphabet, "the window holds the code lengths during the table build");
 
 struct __attribute__((aligned(16))) WaveLds {
@@ -1003,30 +1004,32 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             const uint32_t g0 = g * kRoundMax, g1 = on ? min_u32(round_bytes, g0 + kRoundMax) : g0;
             const uint32_t gpos = out_pos + g0;                         // page position of the group's first byte
 
-            // -- 3b. make room in the window: flush finished bytes (aligned 16-byte stores), then slide,
-            //        keeping kHist >= kWin / 2 bytes of history: every byte flushed by THIS slide is still
-            //        inside the window, so reads from global memory only touch bytes flushed by an earlier
-            //        slide.  `flushed` is 16-byte aligned until the page's last flush and at most kWin bytes lie
-            //        between it and the group, so the flush is two 16-byte pieces per lane; the move brings the
-            //        kHist .. kHist + 15 bytes of history down in one step, all reads before the writes.
+            // -- 3b. flush, and make room in the window when the group does not fit.  Every group first stores the
+            //        finished bytes below it (aligned 16-byte pieces; `flushed` is 16-byte aligned until the page's
+            //        last flush and at most kRoundMax + 15 bytes behind), so that a far copy -- source below the
+            //        window, i.e. more than kHist >= kRoundMax + 16 bytes back -- only ever reads global memory
+            //        written by an EARLIER group's flush.  The slide keeps kHist .. kHist + 15 bytes of history and
+            //        brings them down in one step, all reads before the writes.
             const bool slide = on && out_pos + g1 > view.win_base + kWin && !(kAblate & kAblSlide);
             wave::sync();
-            if (wave::any(slide)) {
-                // all four LDS reads first (two for the flush, two for the move), then the stores
+            {
                 const uint32_t e16 = gpos & ~15u;
                 const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
-                const bool f0 = slide && p0 < e16, f1 = slide && p1 < e16;
+                const bool f0 = on && p0 < e16, f1 = on && p1 < e16;
+                Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0;
+                if (f0) a0 = load16(view.win + (p0 - view.win_base));
+                if (f1) a1 = load16(view.win + (p1 - view.win_base));
+                if (f0) store16(job.out + p0, a0);
+                if (f1) store16(job.out + p1, a1);
+                if (on && e16 > flushed) flushed = e16;
+            }
+            if (wave::any(slide)) {
                 const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
                 const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
                 const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
-                Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0, m0 = a0, m1 = a0;
-                if (f0) a0 = load16(view.win + (p0 - view.win_base));
-                if (f1) a1 = load16(view.win + (p1 - view.win_base));
+                Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0;
                 if (i0 < count) m0 = load16(view.win + shift + i0);
                 if (i1 < count) m1 = load16(view.win + shift + i1);
-                if (f0) store16(job.out + p0, a0);
-                if (f1) store16(job.out + p1, a1);
-                if (slide && e16 > flushed) flushed = e16;
                 wave::sync();
                 if (i0 < count) store16(view.win + i0, m0);
                 if (i1 < count) store16(view.win + i1, m1);
