@@ -167,7 +167,8 @@ struct __attribute__((aligned(16))) PageLds {
     uint32_t start_bits[kRoundMax / 32];    // per group: bit p set <=> a command's piece starts at group byte p
     uint8_t  start_cum[kRoundMax / 32];     // per group: piece starts in earlier words of start_bits
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
-    uint8_t  win[kWin + 48] __attribute__((aligned(16)));   // output window; doubles as the code-length
+    uint32_t ring_push[2][4] __attribute__((aligned(16)));  // the last four distances pushed in a round, most recent first (two rounds alternate)
+    uint8_t  win[kWin + 16] __attribute__((aligned(16)));   // output window; doubles as the code-length
                                                              // scratch (728 B) while tables are built
 };
 constexpr uint32_t kTableScratchBytes = 1024;   // 512-entry code-length LUT, or 16 x 32 counters, as uint16
@@ -177,7 +178,7 @@ static_assert(sizeof(uint16_t) * (1 << kLutBitsLit) + kStageBytes >= kTableScrat
 static_assert(__builtin_offsetof(PageLds, lut_dist) == sizeof(uint16_t) * (1 << kLutBitsIcp), "LUTs must be contiguous");
 static_assert(__builtin_offsetof(PageLds, stage) == sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)), "staging area must follow the LUTs");
 static_assert(kHist + 16u <= 1024u && kWin - kHist >= 512u + 16u, "the slide moves at most two 16-byte pieces per lane; a group fits behind the history");
-static_assert(kWin + 48 >= kIcpAlphabet, "the window holds the code lengths during the table build");
+static_assert(kWin + 16 >= kIcpAlphabet, "the window holds the code lengths during the table build");
 
 struct __attribute__((aligned(16))) WaveLds {
     PageLds  page[2];
@@ -759,6 +760,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
     BitReader br;
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
     uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16;             // PageDecoder.cpp:150-153
+    uint32_t ring_cnt = 0, ring_par = 0;    // pushes of the previous round still to be folded into ring0..3, and where they are
     uint32_t out_pos = 0;            // bytes of the page produced so far
     uint32_t prev_tail = 0;          // literals decoded but not yet consumed
     uint32_t carry_head = 0;
@@ -845,7 +847,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                     build_table(t, L, br, start, sl);
                 }
                 if (start) {
-                    ring0 = 4; ring1 = 11; ring2 = 15; ring3 = 16;
+                    ring0 = 4; ring1 = 11; ring2 = 15; ring3 = 16; ring_cnt = 0;
                     out_pos = 0; prev_tail = 0; carry_head = 0; flushed = 0; bad = false;
                     rounds_left = job.page_size / 64u + 4u;             // every full round emits >= 64 bytes
                     view.win_base = 0u;
@@ -862,6 +864,10 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
         // -- 1. one command per lane.  Two refill points per command: with >= 32 bits in the window the
         //       command symbol (<= 15 bits) leaves >= 17 for the insert/copy extra bits, and likewise the
         //       distance symbol for its extra bits; longer fields (rare) take the general read.
+        // the distances pushed in the previous round (written to LDS by their lanes at the end of its ring step):
+        // read now, folded into the ring when it is needed below
+        Bytes16 pushed = {0u, 0u, 0u, 0u};
+        if (ring_cnt) pushed = *reinterpret_cast<const Bytes16*>(L.ring_push[ring_par ^ 1u]);
         uint32_t sym = 0, len = 0;
         if (live) { br.ensure(32); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
         clk.lap(kPhCmdSym);
@@ -915,6 +921,13 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
         }
         // -- 2. distance ring (PageDecoder.cpp:345-364, :396-403): codes 1..15 are resolved in
         //       command order; explicit distances and code 0 need no serial step
+        {   // new ring = the last four pushed distances (PageDecoder.cpp:396-403)
+            const uint32_t o0 = ring0, o1 = ring1, o2 = ring2;
+            if (ring_cnt >= 4u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = pushed[2]; ring3 = pushed[3]; }
+            else if (ring_cnt == 3u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = pushed[2]; ring3 = o0; }
+            else if (ring_cnt == 2u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = o0; ring3 = o1; }
+            else if (ring_cnt == 1u) { ring0 = pushed[0]; ring1 = o0; ring2 = o1; ring3 = o2; }
+        }
         const bool is_copy = is_cmd && copy > 0u;
         const uint32_t push_mask = wave::half_ballot(is_copy && dcode != 0u);
         // A code 1..15 refers to the r-th most recent push before the command (r from the code): either
@@ -949,21 +962,12 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             const uint32_t below = push_mask & ((1u << sl) - 1u);
             const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
             if (is_copy && dcode == 0u) dist = below ? from : ring0;
-            // new ring = the last four pushed distances
-            uint32_t m = push_mask;
-            const uint32_t cnt = (uint32_t)__popc(m);
-            uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-            if (m) { l0 = msb_u32(m); m &= ~(1u << l0); }
-            if (m) { l1 = msb_u32(m); m &= ~(1u << l1); }
-            if (m) { l2 = msb_u32(m); m &= ~(1u << l2); }
-            if (m) { l3 = msb_u32(m); }
-            const uint32_t d0 = wave::half_bcast(dist, l0), d1 = wave::half_bcast(dist, l1);
-            const uint32_t d2 = wave::half_bcast(dist, l2), d3 = wave::half_bcast(dist, l3);
-            const uint32_t o0 = ring0, o1 = ring1, o2 = ring2;
-            if (cnt >= 4u) { ring0 = d0; ring1 = d1; ring2 = d2; ring3 = d3; }
-            else if (cnt == 3u) { ring0 = d0; ring1 = d1; ring2 = d2; ring3 = o0; }
-            else if (cnt == 2u) { ring0 = d0; ring1 = d1; ring2 = o0; ring3 = o1; }
-            else if (cnt == 1u) { ring0 = d0; ring1 = o0; ring2 = o1; ring3 = o2; }
+            // the round's last four pushes go to LDS, most recent first; the next round folds them into the ring
+            const bool pusher = is_copy && dcode != 0u;
+            const uint32_t above = (uint32_t)__popc((push_mask >> sl) >> 1);    // pushes after mine
+            if (pusher && above < 4u) L.ring_push[ring_par][above] = dist;
+            ring_cnt = (uint32_t)__popc(push_mask);
+            ring_par ^= 1u;
         }
 
         clk.lap(kPhRing);

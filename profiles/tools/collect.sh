@@ -13,6 +13,11 @@ python bench.py > "$out/bench.json" 2> "$out/bench.err"
 python bench.py --workload bc3 --streams 256 --no-cpu-baseline > "$out/bench_bc3.json" 2>> "$out/bench.err"
 python bench.py --workload runs --streams 1 --no-cpu-baseline > "$out/bench_runs.json" 2>> "$out/bench.err"
 python bench.py --workload text --no-cpu-baseline > "$out/bench_text.json" 2>> "$out/bench.err"
+python bench.py --workload samples16 --no-cpu-baseline > "$out/bench_samples16.json" 2>> "$out/bench.err"
+python bench.py --workload records --no-cpu-baseline > "$out/bench_records.json" 2>> "$out/bench.err"
+# every page distinct (about 1 GB of compressed data, beyond the 256 MiB Infinity Cache): does the tiling of 256 pages matter?
+python bench.py --distinct 4096 --no-cpu-baseline > "$out/bench_distinct4096.json" 2>> "$out/bench.err"
+python profiles/tools/latency.py > "$out/latency.json" 2>> "$out/bench.err"
 for k in "mixed 16" "text 16" "runs 16" "bc3 64"; do python profiles/phase_profile.py $k; done > "$out/phase_profile.jsonl" 2>> "$out/bench.err"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o f -- python "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$out/trace.log" 2>&1

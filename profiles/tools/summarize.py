@@ -9,7 +9,7 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 pre = os.path.join(dst, f"r{rnd}_{tag}_")
 
-for name in ("bench", "bench_bc3", "bench_runs", "bench_text"):
+for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16", "bench_records", "bench_distinct4096", "latency"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, pre + name + ".json")
@@ -45,6 +45,7 @@ write, nw = pmc("pmc_write", "WRITE_SIZE")
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 j = {
     "kernel": "brotlig_decode_kernel", "build": label, "workload": bench["config"]["workload"],
+    "kernel_source_sha16": bench["roofline"].get("kernel_source_sha16"),
     "launches_averaged": {"FETCH_SIZE": nf, "WRITE_SIZE": nw},
     "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
     "fetch_bytes_per_launch": fetch * 1024, "write_bytes_per_launch": write * 1024,

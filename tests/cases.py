@@ -62,3 +62,34 @@ def precon_cases():
         out.append((name, (lambda f=fmt, w=w, h=h, m=mips, a=aligned, p=pitch, s=len(out):
                            D.bc_texture(f, w, h, seed=100 + s, num_mips=m, aligned=bool(a), pitch_bytes=p)), pre))
     return out
+
+
+def far_boundary(n, seed, dlo, dhi, lit=8, cpy=24):
+    """Literal runs of `lit` fresh bytes followed by copies of `cpy` bytes from a distance in [dlo, dhi]: with the
+    distances around the decoder's on-chip history (kHist = 528 bytes) every copy reads bytes the window has just
+    given up -- from global memory, where an earlier group of the same wavefront flushed them moments before --
+    or straddles the window boundary."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(n + 64, np.uint8)
+    out[:dhi + 1] = rng.integers(0, 256, dhi + 1, dtype=np.uint8)
+    pos = dhi + 1
+    while pos < n:
+        out[pos:pos + lit] = rng.integers(0, 256, lit, dtype=np.uint8)
+        pos += lit
+        d = int(rng.integers(dlo, dhi + 1))
+        out[pos:pos + cpy] = out[pos - d:pos - d + cpy]
+        pos += cpy
+    return out[:n].copy()
+
+
+def raw_stress_cases():
+    """Global read-after-write inside a wavefront: far copies whose sources were flushed by
+    the previous assembly group.  (name, data thunk, encoder kwargs)."""
+    out = []
+    for k, (dlo, dhi, lit, cpy) in enumerate([(513, 560, 8, 24), (529, 544, 4, 28), (529, 1100, 8, 24), (520, 540, 1, 63),
+                                               (528, 536, 16, 16), (1000, 1100, 8, 120)]):
+        for page in (65536, 131072):
+            out.append((f"far_{dlo}_{dhi}_{lit}_{cpy}_{page >> 10}k",
+                        (lambda a=dlo, b=dhi, l=lit, c=cpy, s=k: far_boundary(4 * 131072 + 777, 40 + s, a, b, l, c)),
+                        dict(page_size=page)))
+    return out

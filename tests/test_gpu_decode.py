@@ -9,7 +9,7 @@ import pytest
 
 from brotli_g_sdk_amd import datagen as D
 from brotli_g_sdk_amd import encoder as E
-from cases import plain_cases, precon_cases
+from cases import plain_cases, precon_cases, raw_stress_cases
 from helpers import oracle_decode
 
 pytestmark = pytest.mark.gpu
@@ -49,6 +49,24 @@ def test_decode_gpu_preconditioned(api, name, thunk, pre):
     assert rc == 0 and np.array_equal(ref, tex)
     out, _ = api.DecodeGPU(stream, output_size=len(tex))
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("name,thunk,kw", raw_stress_cases(), ids=[c[0] for c in raw_stress_cases()])
+def test_far_copies_read_what_the_previous_group_flushed(api, name, thunk, kw):
+    """Global read-after-write inside a wavefront: the decoder keeps 528 bytes of history on chip and flushes the
+    window group by group; copies from 513..1100 bytes back read global memory that the same wavefront stored one
+    group earlier, with no fence in between (the design argument is in brotlig_kernels.h, step 3b).  Four streams
+    side by side so that several wavefronts run the pattern at once; bit-exact against the oracle."""
+    data = thunk()
+    stream = E.encode(data, **kw)
+    rc, ref = oracle_decode(stream)
+    assert rc == 0 and np.array_equal(ref, data)
+    dec = api.BatchDecoder([stream] * 4)
+    for _ in range(3):
+        dec.poison_output()
+        dec.decode()
+        for i in range(4):
+            assert np.array_equal(dec.output(i), ref), (name, i)
 
 
 def test_golden_fixtures_on_gpu(api):

@@ -11,7 +11,7 @@ import pytest
 
 from brotli_g_sdk_amd import datagen as D
 from brotli_g_sdk_amd import encoder as E
-from cases import plain_cases, precon_cases
+from cases import plain_cases, precon_cases, raw_stress_cases
 from helpers import ROOT, oracle_decode
 
 SIM_DIR = os.path.join(ROOT, "tests", "sim")
@@ -146,3 +146,15 @@ def test_sim_page_schedule_on_and_off(sim):
                 assert np.array_equal(o, d)
     finally:
         sim.sim_set_order(1)
+
+
+@pytest.mark.parametrize("name,thunk,kw", raw_stress_cases()[::3], ids=[c[0] for c in raw_stress_cases()[::3]])
+def test_sim_far_boundary(sim, name, thunk, kw):
+    """Copies from just beyond the on-chip history (far sources, straddling sources): logic check on the simulator;
+    the memory-ordering side of it is tests/test_gpu_decode.py::test_far_copies_read_what_the_previous_group_flushed."""
+    data = thunk()
+    stream = E.encode(data, **kw)
+    rc, ref = oracle_decode(stream)
+    assert rc == 0 and np.array_equal(ref, data)
+    outs, status = run_batch(sim, [stream], [len(data)])
+    assert status == 0 and np.array_equal(outs[0], ref)
