@@ -1059,40 +1059,41 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             // the first far_len bytes of the pattern lie below the window: fetched from global memory
             // into the staging area (loads issued now, consumed after the literal decode)
             const uint32_t far_len = (plen && psrc < view.win_base && !(kAblate & kAblFar)) ? min_u32(pattern, view.win_base - psrc) : 0u;
-            const uint32_t stage_len = (far_len + 7u) & ~7u;
-            const uint32_t stage_incl = wave::half_scan_incl(stage_len);
-            const uint32_t stage_off = stage_incl - stage_len;          // 8-byte aligned offset into L.stage
-            // far loads are issued now and consumed after the literal decode.  Usual case (no far piece
-            // longer than 32 bytes): each lane fetches its own piece, up to four 8-byte chunks.  Otherwise
-            // every far piece gets a team of lanes, two chunks per lane now and the remainder later.
-            const uint32_t far_mask = wave::half_ballot(far_len != 0u);
-            const bool far_teams = wave::any(far_len > kShortCopy);
-            uint64_t fe0 = 0, fe1 = 0, fe2 = 0, fe3 = 0;
+            // A piece that lies below the window as a whole, does not overlap itself and is at most kShortCopy bytes
+            // long (far_len == plen) never touches the staging area: its own lane fetches it and its bytes go from
+            // these registers straight to their place in the window once the literals are decoded.  Pieces of 8 bytes
+            // and more are covered by 8-byte chunks at offsets 0, 8, 16, 24 clipped to plen - 8 (the last chunk ends
+            // exactly at the piece's end and overlaps its predecessor); shorter ones by one load and a split store.
+            // Everything else that reaches below the window is staged: longer pieces, and patterns that straddle
+            // the window boundary.  Staged pieces of up to kShortCopy bytes are fetched by their own lane too; as
+            // soon as one is longer, all staged pieces get teams of lanes (two chunks per lane now, the rest later).
+            const bool far_direct = far_len != 0u && far_len == plen && plen <= kShortCopy;
+            const bool staged = far_len != 0u && !far_direct;
+            const uint32_t stage_len = staged ? (far_len + 7u) & ~7u : 0u;
+            const bool any_staged = wave::any(staged);
+            uint32_t stage_off = 0;                                     // 8-byte aligned offset into L.stage
+            if (any_staged) stage_off = wave::half_scan_incl(stage_len) - stage_len;
+            const bool far_teams = any_staged && wave::any(staged && far_len > kShortCopy);
+            uint64_t fe0 = 0, fe1 = 0, fe2 = 0, fe3 = 0, te0 = 0, te1 = 0;
             Team ft{5u, 0u, 0u, false};
             uint32_t ft_src = 0, ft_len = 0, ft_stage = 0;
-            // A piece that lies below the window as a whole and does not overlap itself (far_len == plen; at most
-            // kShortCopy bytes on this path) never touches the staging area: its bytes go from these registers
-            // straight to their place in the window once the literals are decoded.  Pieces of 8 bytes and more are
-            // covered by 8-byte chunks at offsets 0, 8, 16, 24 clipped to plen - 8 (the last chunk ends exactly at
-            // the piece's end and overlaps its predecessor); shorter ones by one load and a split store.
-            const bool far_direct = !far_teams && far_len != 0u && far_len == plen;
             const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
-            if (!far_teams) {
-                if (far_len) {
-                    const uint8_t* s8 = job.out + psrc;
-                    const uint32_t lim = far_direct ? clip8 : 24u;      // a straddling piece keeps plain offsets (staged)
-                    fe0 = load_u64u(s8);
-                    if (far_len > 8u) fe1 = load_u64u(s8 + min_u32(8u, lim));
-                    if (far_len > 16u) fe2 = load_u64u(s8 + min_u32(16u, lim));
-                    if (far_len > 24u) fe3 = load_u64u(s8 + min_u32(24u, lim));
-                }
-            } else {
-                ft = make_team(far_mask, sl);
+            if (far_len != 0u && (far_direct || !far_teams)) {
+                const uint8_t* s8 = job.out + psrc;
+                const uint32_t lim = far_direct ? clip8 : 24u;          // a staged piece keeps plain offsets
+                fe0 = load_u64u(s8);
+                if (far_len > 8u) fe1 = load_u64u(s8 + min_u32(8u, lim));
+                if (far_len > 16u) fe2 = load_u64u(s8 + min_u32(16u, lim));
+                if (far_len > 24u) fe3 = load_u64u(s8 + min_u32(24u, lim));
+            }
+            if (far_teams) {
+                const uint32_t staged_mask = wave::half_ballot(staged);
+                ft = make_team(staged_mask, sl);
                 ft_src = wave::half_shfl(psrc, ft.job); ft_len = wave::half_shfl(far_len, ft.job);
                 ft_stage = wave::half_shfl(stage_off, ft.job);
-                ft.serves = ft.serves && far_mask != 0u;
-                if (ft.serves && 8u * ft.member < ft_len) fe0 = load_u64u(job.out + ft_src + 8u * ft.member);
-                if (ft.serves && 8u * (ft.member + (1u << ft.log2_size)) < ft_len) fe1 = load_u64u(job.out + ft_src + 8u * (ft.member + (1u << ft.log2_size)));
+                ft.serves = ft.serves && staged_mask != 0u;
+                if (ft.serves && 8u * ft.member < ft_len) te0 = load_u64u(job.out + ft_src + 8u * ft.member);
+                if (ft.serves && 8u * (ft.member + (1u << ft.log2_size)) < ft_len) te1 = load_u64u(job.out + ft_src + 8u * (ft.member + (1u << ft.log2_size)));
             }
             clk.lap(kPhPieces);
             // literals of the group: consumption indices [F0, F1)
@@ -1200,28 +1201,31 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
             //        staging area (aligned 8-byte LDS writes)
             const uint32_t src_idx = psrc - view.win_base;              // window index of the pattern start (negative when far)
             const uint32_t dst_idx = pdst - view.win_base;
-            if (!far_teams) {
-                if (far_direct) {
-                    uint8_t* d = L.win + dst_idx;
-                    if (plen >= 8u) {
-                        __builtin_memcpy(d, &fe0, 8);
-                        if (plen > 8u) __builtin_memcpy(d + min_u32(8u, clip8), &fe1, 8);
-                        if (plen > 16u) __builtin_memcpy(d + min_u32(16u, clip8), &fe2, 8);
-                        if (plen > 24u) __builtin_memcpy(d + clip8, &fe3, 8);
-                    } else store_bytes(d, fe0, plen);
-                } else if (far_len) {
-                    uint64_t* st = &L.stage[stage_off >> 3];
-                    st[0] = fe0;
-                    if (far_len > 8u) st[1] = fe1;
-                    if (far_len > 16u) st[2] = fe2;
-                    if (far_len > 24u) st[3] = fe3;
-                }
-            } else {
-                const uint32_t tsz = 1u << ft.log2_size;
-                if (ft.serves && 8u * ft.member < ft_len) L.stage[(ft_stage >> 3) + ft.member] = fe0;
-                if (ft.serves && 8u * (ft.member + tsz) < ft_len) L.stage[(ft_stage >> 3) + ft.member + tsz] = fe1;
-                for (uint32_t c = ft.member + 2u * tsz; wave::any(ft.serves && 8u * c < ft_len); c += tsz) {
-                    if (ft.serves && 8u * c < ft_len) L.stage[(ft_stage >> 3) + c] = load_u64u(job.out + ft_src + 8u * c);
+            if (far_direct) {
+                uint8_t* d = L.win + dst_idx;
+                if (plen >= 8u) {
+                    __builtin_memcpy(d, &fe0, 8);
+                    if (plen > 8u) __builtin_memcpy(d + min_u32(8u, clip8), &fe1, 8);
+                    if (plen > 16u) __builtin_memcpy(d + min_u32(16u, clip8), &fe2, 8);
+                    if (plen > 24u) __builtin_memcpy(d + clip8, &fe3, 8);
+                } else store_bytes(d, fe0, plen);
+            }
+            if (any_staged) {
+                if (!far_teams) {
+                    if (staged) {
+                        uint64_t* st = &L.stage[stage_off >> 3];
+                        st[0] = fe0;
+                        if (far_len > 8u) st[1] = fe1;
+                        if (far_len > 16u) st[2] = fe2;
+                        if (far_len > 24u) st[3] = fe3;
+                    }
+                } else {
+                    const uint32_t tsz = 1u << ft.log2_size;
+                    if (ft.serves && 8u * ft.member < ft_len) L.stage[(ft_stage >> 3) + ft.member] = te0;
+                    if (ft.serves && 8u * (ft.member + tsz) < ft_len) L.stage[(ft_stage >> 3) + ft.member + tsz] = te1;
+                    for (uint32_t c = ft.member + 2u * tsz; wave::any(ft.serves && 8u * c < ft_len); c += tsz) {
+                        if (ft.serves && 8u * c < ft_len) L.stage[(ft_stage >> 3) + c] = load_u64u(job.out + ft_src + 8u * c);
+                    }
                 }
             }
             wave::sync();
