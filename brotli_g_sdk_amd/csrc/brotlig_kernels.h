@@ -11,11 +11,16 @@
 //     (BrotliGCompute.hlsl:500-526) or the CPU's three 64 KiB tables (BrotligHuffmanTable.cpp:44-71);
 //   * each lane streams its own sub-bitstream from global memory through a 64-bit window, 64 queued
 //     bits and 64 bits in flight;
-//   * literals are routed straight to their output position (no literal FIFO);
-//   * the page is assembled in an LDS window; the LZ77 copies of a round run in dependency levels
-//     computed exactly (which earlier pieces own bytes of my source range), one lane per command
-//     or in teams of lanes for long copies (the shader walks the 32 commands serially,
-//     BrotliGCompute.hlsl:1401-1419);
+//   * the round's literals are decoded into a small queue in LDS (consumption order, one assembly group at a
+//     time) and every command moves its own literal run to the window like a short copy;
+//   * the page is assembled in an LDS window (1.5 KiB, flushed group by group in 16-byte stores); a copy
+//     whose source has left the window is fetched from global memory by its own lane while the literals are
+//     being decoded and goes from registers straight to its place; the remaining LZ77 copies of a round run
+//     in dependency levels computed exactly (which earlier pieces own bytes of my source range), one lane
+//     per command in 8-byte chunks, or in teams of lanes for long copies (the shader walks the 32 commands
+//     serially, BrotliGCompute.hlsl:1401-1419);
+//   * the distance ring travels from round to round through LDS (the last four pushes of a round, written by
+//     their lanes) instead of being rebuilt from lane broadcasts;
 //   * work is pulled from one device-side counter by persistent waves, through a page schedule
 //     that puts similar pages side by side (order kernels below).
 //
@@ -505,7 +510,11 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
     const uint32_t s2 = wave::half_bcast(mysym, 2), s3 = wave::half_bcast(mysym, 3);
     // -- complex: code-length code, then RLE-coded code lengths
     if (wave::any(is_complex)) {
-        // 18 code-length-code lengths, the k-th from sub-stream k, for symbols in a fixed order
+        // 18 code-length-code lengths, the k-th from sub-stream k, for symbols in a fixed order.  Fewer than 18
+        // (header field < 14) is undefined in the reference: it builds the code-length table over the first ncl
+        // symbol INDICES of an array whose other entries were never written (uninitialised stack,
+        // BrotligHuffmanTable.cpp:125,:141), and its encoder always writes 18 (src/encoder/BrotligHuffman.cpp:358).
+        // Here every length that was read gets its code.
         const uint32_t ncl = min_u32(((hdr >> 2) & 15u) + 4u, 18u);
         uint32_t cl_len = 0;
         const uint32_t cl_sym = sl < 18u ? kCodeLenOrder[sl] : 31u;
