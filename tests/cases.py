@@ -70,7 +70,7 @@ def far_boundary(n, seed, dlo, dhi, lit=8, cpy=24):
     given up -- from global memory, where an earlier group of the same wavefront flushed them moments before --
     or straddles the window boundary."""
     rng = np.random.default_rng(seed)
-    out = np.empty(n + 64, np.uint8)
+    out = np.empty(n + lit + cpy + 64, np.uint8)
     out[:dhi + 1] = rng.integers(0, 256, dhi + 1, dtype=np.uint8)
     pos = dhi + 1
     while pos < n:
