@@ -33,6 +33,7 @@ def plain_cases():
         ("text_32k_pages", lambda: D.text(N, 14), dict(page_size=32768)),
         ("mixed_128k_pages", lambda: D.mixed(3 * 65536 + 77, 15), dict(page_size=131072)),
         ("skewed_long_codes", lambda: skewed(N, 16), {}),
+        ("deep_literal_codes", lambda: np.minimum(np.random.default_rng(21).geometric(0.05, 200000) - 1, 255).astype(np.uint8), {}),   # 15-bit literal codes: their sub-tables overflow the page's second-level pool (canonical fallback)
         ("long_matches", lambda: np.tile(D.random_bytes(5000, 17), 40)[:N], {}),
         ("period_1_2_3", lambda: np.concatenate([np.full(30000, 7, np.uint8), np.tile(np.array([1, 2], np.uint8), 20000),
                                                  np.tile(np.array([9, 8, 7], np.uint8), 15000)]), {}),
