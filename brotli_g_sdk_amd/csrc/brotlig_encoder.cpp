@@ -445,20 +445,41 @@ void parse_page_optimal(const uint8_t* data, uint32_t n, const BrotligEncodeOpti
         starts[k] = i;
         while (k > 0 && key(starts[k - 1]) > key(starts[k])) { std::swap(starts[k - 1], starts[k]); --k; }
     };
-    auto relax = [&](uint32_t i, uint32_t p, uint32_t len, uint32_t dist) {
+    // Edge costs are split into what depends on the start (insert code, literals), on start and distance (distance
+    // symbol) and on the copy length (copy code, the ICP symbol), so that walking the lengths of one match from one
+    // start is a table lookup and a compare per length.
+    static const std::vector<uint8_t> copy_code = [] {
+        std::vector<uint8_t> t(2200);
+        for (uint32_t l = 0; l < t.size(); ++l) t[l] = (uint8_t)code_of(kCopyBase, l < 2 ? 2 : l);
+        return t;
+    }();
+    auto cc_of = [&](uint32_t len) { return len < copy_code.size() ? (uint32_t)copy_code[len] : code_of(kCopyBase, len); };
+    std::vector<float> cmd_cost(24 * 24 * 2);                           // [insert code][copy code][implicit]: ICP symbol + copy extra bits
+    for (uint32_t ic = 0; ic < 24; ++ic)
+        for (uint32_t cc = 0; cc < 24; ++cc)
+            for (uint32_t im = 0; im < 2; ++im)
+                cmd_cost[(ic * 24 + cc) * 2 + im] = (im && !(ic < 8 && cc < 16)) ? kInf
+                                                    : cm.icp[icp_symbol(ic, cc, im != 0)] + (float)kCopyExtra[cc];
+    auto relax_range = [&](uint32_t i, uint32_t p, uint32_t lmin, uint32_t lmax, uint32_t dist) {
         const PathNode& a = node[i];
         const uint32_t ins = p - i;
-        const uint32_t ic = code_of(kInsBase, ins), cc = code_of(kCopyBase, len);
+        const uint32_t ic = code_of(kInsBase, ins);
         uint32_t nb, ex;
         const int code = distance_code(dist, a.ring, npostfix, ndirect, use_ring, nb, ex);
-        const bool implicit = code == 0 && ic < 8 && cc < 16;
-        float c = a.cost + (litcum[p] - litcum[i]) + cm.icp[icp_symbol(ic, cc, implicit)] + (float)(kInsExtra[ic] + kCopyExtra[cc]);
-        if (!implicit) c += cm.dist[code] + (float)nb;
-        PathNode& b = node[p + len];
-        if (c < b.cost) {
-            b.cost = c; b.from = i; b.ins = ins; b.len = len; b.dist = dist;
-            if (code != 0) { b.ring[0] = dist; b.ring[1] = a.ring[0]; b.ring[2] = a.ring[1]; b.ring[3] = a.ring[2]; }
-            else { b.ring[0] = a.ring[0]; b.ring[1] = a.ring[1]; b.ring[2] = a.ring[2]; b.ring[3] = a.ring[3]; }
+        const float base = a.cost + (litcum[p] - litcum[i]) + (float)kInsExtra[ic];
+        const float dcost = cm.dist[code] + (float)nb;
+        const bool can_implicit = code == 0 && ic < 8;
+        const float* row = &cmd_cost[ic * 24 * 2];
+        for (uint32_t len = lmin; len <= lmax; ++len) {
+            const uint32_t cc = cc_of(len);
+            const bool implicit = can_implicit && cc < 16;
+            const float c = base + row[cc * 2 + (implicit ? 1 : 0)] + (implicit ? 0.f : dcost);
+            PathNode& b = node[p + len];
+            if (c < b.cost) {
+                b.cost = c; b.from = i; b.ins = ins; b.len = len; b.dist = dist;
+                if (code != 0) { b.ring[0] = dist; b.ring[1] = a.ring[0]; b.ring[2] = a.ring[1]; b.ring[3] = a.ring[2]; }
+                else { b.ring[0] = a.ring[0]; b.ring[1] = a.ring[1]; b.ring[2] = a.ring[2]; b.ring[3] = a.ring[3]; }
+            }
         }
     };
     for (uint32_t p = 0; p < n; ++p) {
@@ -490,8 +511,8 @@ void parse_page_optimal(const uint8_t* data, uint32_t n, const BrotligEncodeOpti
             longest = std::max(longest, L);
             for (int si = 0; si < nstarts; ++si) {
                 const uint32_t i = starts[si];
-                if (L >= 96) { relax(i, p, L, dist); continue; }           // long match: whole length only
-                for (uint32_t l = (dist == node[i].ring[0] ? 2u : std::min(L, 4u)); l <= L; ++l) relax(i, p, l, dist);
+                if (L >= 96) { relax_range(i, p, L, L, dist); continue; }  // long match: whole length only
+                relax_range(i, p, dist == node[i].ring[0] ? 2u : std::min(L, 4u), L, dist);
             }
         }
         P.insert(p);
