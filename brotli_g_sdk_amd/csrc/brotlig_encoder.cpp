@@ -167,6 +167,51 @@ void rle_tokens(const std::vector<uint8_t>& depth, bool use_rle, std::vector<Tok
     }
 }
 
+// Smooth population counts so that the code lengths built from them form longer runs (fewer tokens in the
+// description).  In the spirit of brotli's BrotliOptimizeHuffmanCountsForRle (which the reference calls,
+// src/encoder/PageEncoder.cpp:430-437), restated freely: stretches of existing long runs are left alone;
+// elsewhere, neighbouring counts that stay within a band around their running mean are replaced by that mean.
+// A symbol that occurs keeps a non-zero count; symbols inside a smoothed stretch may gain one.
+void smooth_counts_for_rle(std::vector<uint32_t>& c)
+{
+    size_t n = c.size();
+    while (n > 0 && c[n - 1] == 0) --n;                                // trailing zeros stay zeros
+    size_t nonzero = 0;
+    for (size_t i = 0; i < n; ++i) nonzero += c[i] != 0;
+    if (nonzero < 16) return;
+    // runs that already encode well: >= 5 zeros, or >= 7 equal non-zero counts
+    std::vector<uint8_t> keep(n, 0);
+    for (size_t i = 0; i < n;) {
+        size_t j = i;
+        while (j < n && c[j] == c[i]) ++j;
+        if ((c[i] == 0 && j - i >= 5) || (c[i] != 0 && j - i >= 7)) for (size_t k = i; k < j; ++k) keep[k] = 1;
+        i = j;
+    }
+    auto close = [&](size_t from, size_t to, uint64_t sum) {          // [from, to): replace by the mean
+        const size_t len = to - from;
+        if (len < 4 && !(len == 3 && sum == 0)) return;
+        uint32_t mean = (uint32_t)((sum + len / 2) / len);
+        if (mean == 0 && sum != 0) mean = 1;
+        for (size_t k = from; k < to; ++k) c[k] = (sum == 0) ? 0u : std::max<uint32_t>(mean, 1u);
+    };
+    size_t from = 0; uint64_t sum = 0;
+    for (size_t i = 0; i <= n; ++i) {
+        bool brk = i == n || keep[i] || (i > from && keep[i - 1]);
+        if (!brk && i > from) {
+            // band: within ~40 % + 2 of the stretch's mean so far; zeros and non-zeros do not mix
+            const double mean = (double)sum / (double)(i - from);
+            const double lo = mean * 0.6 - 2.0, hi = mean * 1.4 + 2.0;
+            if ((double)c[i] < lo || (double)c[i] > hi || ((c[i] == 0) != (sum == 0))) brk = true;
+        }
+        if (brk) {
+            if (i > from) close(from, i, sum);
+            from = i; sum = 0;
+            if (i < n && keep[i]) { from = i + 1; continue; }
+        }
+        if (i < n) sum += c[i];
+    }
+}
+
 // Emit one prefix-code description (ICP / distance / literal) and return the code to use.
 PrefixCode emit_prefix_code(Streams& S, const std::vector<uint32_t>& hist, uint32_t flags)
 {
@@ -210,27 +255,45 @@ PrefixCode emit_prefix_code(Streams& S, const std::vector<uint32_t>& hist, uint3
         S.reset();
         return pc;
     }
-    // complex
-    huffman_lengths(hist, 15, pc.depth);
-    if (used.size() == 1) { pc.depth[used[0]] = 1; }                  // only reachable with force_complex
-    if (used.size() < 2) {                                             // a 1-symbol complex code is incomplete: add a dummy
-        uint32_t other = used[0] == 0 ? 1 : 0;
-        pc.depth[other] = 1;
+    // complex.  plan(): code lengths from `counts`, their RLE tokens and the code-length code; returns the bits the
+    // description plus the coded symbols (true counts) will take.
+    std::vector<Token> toks;
+    std::vector<uint8_t> tdepth; std::vector<uint16_t> tcode;
+    auto plan = [&](const std::vector<uint32_t>& counts, std::vector<uint8_t>& depth, std::vector<Token>& tk,
+                    std::vector<uint8_t>& td, std::vector<uint16_t>& tc) -> uint64_t {
+        huffman_lengths(counts, 15, depth);
+        if (used.size() == 1) { depth[used[0]] = 1; }                  // only reachable with force_complex
+        if (used.size() < 2) {                                         // a 1-symbol complex code is incomplete: add a dummy
+            uint32_t other = used[0] == 0 ? 1 : 0;
+            depth[other] = 1;
+        }
+        rle_tokens(depth, !(flags & BROTLIG_ENC_NO_CODELEN_RLE), tk);
+        std::vector<uint32_t> thist(18, 0);
+        for (auto& t : tk) ++thist[t.sym];
+        uint32_t distinct = 0; for (uint32_t c : thist) distinct += c != 0;
+        if (distinct < 2) {                                            // Appendix D.6: never a 1-symbol code-length code
+            rle_tokens(depth, true, tk);
+            std::fill(thist.begin(), thist.end(), 0);
+            for (auto& t : tk) ++thist[t.sym];
+        }
+        huffman_lengths(thist, 7, td);                                 // <= 7: BrotliGCompute.hlsl:58
+        canonical_codes(td, tc);
+        uint64_t bits = 6 + 18 * 5;
+        for (auto& t : tk) bits += td[t.sym] + (t.sym == 16 ? 2 : t.sym == 17 ? 3 : 0);
+        for (uint32_t sy = 0; sy < alphabet; ++sy) bits += (uint64_t)hist[sy] * depth[sy];
+        return bits;
+    };
+    uint64_t best_bits = plan(hist, pc.depth, toks, tdepth, tcode);
+    if (flags & BROTLIG_ENC_SMOOTH_HISTOGRAMS) {
+        // the reference smooths the counts before building the code (src/encoder/PageEncoder.cpp:430-437 calls
+        // brotli's BrotliOptimizeHuffmanCountsForRle); here the smoothed counts are kept only when they pay
+        std::vector<uint32_t> smooth = hist;
+        smooth_counts_for_rle(smooth);
+        std::vector<uint8_t> d2, td2; std::vector<Token> tk2; std::vector<uint16_t> tc2;
+        const uint64_t b2 = plan(smooth, d2, tk2, td2, tc2);
+        if (b2 < best_bits) { best_bits = b2; pc.depth = d2; toks = tk2; tdepth = td2; tcode = tc2; }
     }
     canonical_codes(pc.depth, pc.code);
-    std::vector<Token> toks;
-    rle_tokens(pc.depth, !(flags & BROTLIG_ENC_NO_CODELEN_RLE), toks);
-    std::vector<uint32_t> thist(18, 0);
-    for (auto& t : toks) ++thist[t.sym];
-    uint32_t distinct = 0; for (uint32_t c : thist) distinct += c != 0;
-    if (distinct < 2) {                                                // Appendix D.6: never a 1-symbol code-length code
-        rle_tokens(pc.depth, true, toks);
-        std::fill(thist.begin(), thist.end(), 0);
-        for (auto& t : toks) ++thist[t.sym];
-    }
-    std::vector<uint8_t> tdepth; std::vector<uint16_t> tcode;
-    huffman_lengths(thist, 7, tdepth);                                 // <= 7: BrotliGCompute.hlsl:58
-    canonical_codes(tdepth, tcode);
     static const uint8_t order[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
     S.at().put(2, 2); S.at().put(18 - 4, 4);
     for (uint32_t k = 0; k < 18; ++k) { S.at().put(tdepth[order[k]], 5); S.next(); }

@@ -26,7 +26,8 @@ enum {
     BROTLIG_ENC_LITERALS_ONLY       = 1u << 4,  /* no matches: one insert-only command */
     BROTLIG_ENC_FORCE_COMPLEX_TABLES= 1u << 5,  /* complex description even for 2..4 symbols */
     BROTLIG_ENC_SEARCH_DIST_PARAMS  = 1u << 6,  /* per page: pick NPOSTFIX / NDIRECT by estimated distance cost */
-    BROTLIG_ENC_OPTIMAL_PARSE       = 1u << 7   /* shortest-path parse under the symbol costs of a first (lazy) parse */
+    BROTLIG_ENC_OPTIMAL_PARSE       = 1u << 7,  /* shortest-path parse under the symbol costs of a first (lazy) parse */
+    BROTLIG_ENC_SMOOTH_HISTOGRAMS   = 1u << 8   /* smooth symbol counts so that the code lengths run-length encode better (kept per code only when smaller) */
 };
 
 typedef struct BrotligEncodeOptions {

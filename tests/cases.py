@@ -30,6 +30,7 @@ def plain_cases():
         ("all_stored", lambda: D.text(N, 13), dict(flags=E.FORCE_STORED)),
         ("mixed_optimal_parse", lambda: D.mixed(3 * 65536 + 500, 19), dict(flags=E.OPTIMAL_PARSE | E.SEARCH_DIST_PARAMS)),
         ("mixed_dist_param_search", lambda: D.mixed(5 * 65536, 18), dict(flags=E.SEARCH_DIST_PARAMS)),    # NPOSTFIX / NDIRECT vary per page
+        ("records_smoothed_histograms", lambda: D.records(N, 22), dict(flags=E.SMOOTH_HISTOGRAMS)),       # code lengths with longer runs (more 16 / 17 tokens)
         ("text_32k_pages", lambda: D.text(N, 14), dict(page_size=32768)),
         ("mixed_128k_pages", lambda: D.mixed(3 * 65536 + 77, 15), dict(page_size=131072)),
         ("skewed_long_codes", lambda: skewed(N, 16), {}),

@@ -125,7 +125,7 @@ int compress(const Options& o, const std::vector<uint8_t>& src)
     BrotligEncodeOptions e{};
     e.page_size = o.page_size;
     // best ratio by default: shortest-path parse and per-page NPOSTFIX / NDIRECT search; -fast keeps the lazy parse
-    e.flags = o.fast ? 0u : (BROTLIG_ENC_SEARCH_DIST_PARAMS | BROTLIG_ENC_OPTIMAL_PARSE);
+    e.flags = o.fast ? 0u : (BROTLIG_ENC_SEARCH_DIST_PARAMS | BROTLIG_ENC_OPTIMAL_PARSE | BROTLIG_ENC_SMOOTH_HISTOGRAMS);
     if (o.precondition) {
         if (o.format < 1 || o.format > 5 || !o.tex_width || !o.tex_height) {
             fprintf(stderr, "brotlig: -precondition needs -data-format 1..5, -texture-width and -texture-height\n");
