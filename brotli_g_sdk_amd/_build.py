@@ -10,6 +10,7 @@ ROOT = os.path.dirname(HERE)
 
 ENC_SO = os.path.join(CSRC, "libbrotlig_enc.so")
 HIP_SO = os.path.join(CSRC, "libbrotlig_hip.so")
+CPU_SO = os.path.join(CSRC, "libbrotlig_cpu.so")
 
 
 def _stale(target, sources):
@@ -28,6 +29,15 @@ def build_encoder(force=False):
     if force or _stale(ENC_SO, src):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-o", ENC_SO, src[0]], cwd=CSRC)
     return ENC_SO
+
+
+def build_cpu(force=False):
+    """DecodeCPU of the reference API (inc/BrotligDecoder.h:33): its own library, never loaded by the GPU path."""
+    src = [os.path.join(CSRC, "brotlig_cpu.cpp"), os.path.join(CSRC, "brotlig_format.h"), os.path.join(ROOT, "include", "brotlig_amd.h")]
+    if force or _stale(CPU_SO, src):
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"),
+                               "-I", CSRC, "-o", CPU_SO, src[0]], cwd=CSRC)
+    return CPU_SO
 
 
 def hip_sources():
@@ -51,15 +61,17 @@ CLI_BIN = os.path.join(ROOT, "tools", "brotlig")
 
 
 def build_cli(force=False):
-    """The portable command-line tool (tools/brotlig_cli.cpp), linked against the two in-tree libraries."""
+    """The portable command-line tool (tools/brotlig_cli.cpp), linked against the in-tree libraries."""
     src = os.path.join(ROOT, "tools", "brotlig_cli.cpp")
-    if force or _stale(CLI_BIN, [src, ENC_SO, HIP_SO]):
+    build_cpu()
+    if force or _stale(CLI_BIN, [src, ENC_SO, HIP_SO, CPU_SO]):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", CLI_BIN, src,
-                               "-L", CSRC, "-lbrotlig_enc", "-lbrotlig_hip", "-pthread", "-Wl,-rpath,$ORIGIN/../brotli_g_sdk_amd/csrc"])
+                               "-L", CSRC, "-lbrotlig_enc", "-lbrotlig_hip", "-lbrotlig_cpu", "-pthread", "-Wl,-rpath,$ORIGIN/../brotli_g_sdk_amd/csrc"])
     return CLI_BIN
 
 
 def build_all(force=False):
     build_encoder(force)
     build_hip(force)
+    build_cpu(force)
     build_cli(force)

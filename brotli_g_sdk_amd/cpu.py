@@ -1,0 +1,37 @@
+"""Host-side mirror of the reference's CPU decode entry (`DecodeCPU`, inc/BrotligDecoder.h:33) over
+libbrotlig_cpu.so (include/brotlig_amd_cpu.h).  Deliberately not part of `api`: the GPU path never imports this
+module and has no CPU fallback."""
+import ctypes
+
+import numpy as np
+
+from . import _build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(_build.build_cpu())
+        L.DecompressedSize.restype = ctypes.c_uint32
+        L.DecompressedSize.argtypes = [ctypes.c_void_p]
+        L.DecodeCPU.restype = ctypes.c_int
+        L.DecodeCPU.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p, ctypes.c_void_p]
+        L.BrotligDecodeCPU.restype = ctypes.c_int
+        L.BrotligDecodeCPU.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p, ctypes.c_uint32]
+        _lib = L
+    return _lib
+
+
+def DecodeCPU(src, output_size=None, workers=None):
+    """BROTLIG_ERROR DecodeCPU(input_size, src, output_size, output, feedbackProc).  Returns (code, output ndarray)."""
+    a = np.ascontiguousarray(np.frombuffer(src, dtype=np.uint8) if not isinstance(src, np.ndarray) else src, dtype=np.uint8)
+    cap = int(lib().DecompressedSize(a.ctypes.data)) if output_size is None and len(a) >= 8 else int(output_size or 0)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    osz = ctypes.c_uint32(cap)
+    if workers is None:
+        rc = lib().DecodeCPU(len(a), a.ctypes.data, ctypes.byref(osz), out.ctypes.data, None)
+    else:
+        rc = lib().BrotligDecodeCPU(len(a), a.ctypes.data, ctypes.byref(osz), out.ctypes.data, int(workers))
+    return rc, out[:osz.value] if rc == 0 else out[:0]

@@ -1,0 +1,30 @@
+/* brotlig_amd_cpu.h -- CPU decode entry of the drop-in boundary, exported by libbrotlig_cpu.so
+ * (brotli_g_sdk_amd/csrc/brotlig_cpu.cpp).  A library of its own: libbrotlig_hip.so (brotlig_amd.h) is
+ * GPU-only, never loads this one and has no CPU fallback.  Plain C. */
+#ifndef BROTLIG_AMD_CPU_H
+#define BROTLIG_AMD_CPU_H
+#include "brotlig_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Replaces: BROTLIG_ERROR BrotliG::DecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size,
+ *                                            uint8_t* output, BROTLIG_Feedback_Proc feedbackProc)
+ *   inc/BrotligDecoder.h:33, src/BrotligDecoder.cpp:495-519 (-> :426-493).
+ * Host pointers.  *output_size = capacity of `output` on entry (for a pre-conditioned stream exactly the texture
+ * size, src/BrotligDecoder.cpp:478), decompressed size on return.  Pages are decoded on up to 128 threads
+ * (inc/common/BrotligConstants.h:90).  `feedbackProc`: the reference's callback takes a std::string and cannot
+ * cross a C boundary; pass NULL (anything else is ignored).
+ * Errors: BROTLIG_ERROR_CORRUPT_STREAM (magic), BROTLIG_ERROR_INCORRECT_STREAM_FORMAT (id != 5) as
+ * src/BrotligDecoder.cpp:437-446; BROTLIG_ERROR_GENERIC for a page that fails a bounds check or an output
+ * buffer of the wrong size (undefined behaviour in the reference).  Only bytes of `src` inside input_size are read. */
+BROTLIG_ERROR DecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, void* feedbackProc);
+
+/* The same with an explicit thread count (0 = one per hardware thread, at most one per page). */
+BROTLIG_ERROR BrotligDecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, uint32_t workers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

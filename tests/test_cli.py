@@ -47,6 +47,20 @@ def test_cli_rejects_bad_usage(cli, tmp_path):
     assert subprocess.run([cli, "-precondition", str(src)], capture_output=True).returncode == 2      # format / size missing
 
 
+def test_cli_cpu_round_trip(cli, tmp_path):
+    """`-cpu` decompresses with DecodeCPU (libbrotlig_cpu.so): an explicit choice, never a fallback."""
+    for name, data, extra in (("a.bin", D.mixed(65536 * 5 + 123, 3), []),
+                              ("t.bin", D.bc_texture(3, 64, 64, seed=2), ["-precondition", "-swizzle", "-delta-encode", "-data-format", "3",
+                                                                         "-texture-width", "256", "-texture-height", "256"])):
+        src = tmp_path / name
+        data.tofile(src)
+        assert subprocess.run([cli] + extra + [str(src)], capture_output=True).returncode == 0
+        os.rename(src, str(src) + ".orig")
+        r = subprocess.run([cli, "-cpu", "-num-repeat", "2", str(src) + ".brotlig"], capture_output=True, text=True)
+        assert r.returncode == 0 and "on the CPU" in r.stdout, r.stderr
+        assert np.array_equal(np.fromfile(src, dtype=np.uint8), data)
+
+
 @pytest.mark.gpu
 def test_cli_round_trip_on_gpu(cli, tmp_path):
     """compress, then `brotlig file.brotlig` decompresses on the GPU to the original bytes."""

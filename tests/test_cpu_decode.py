@@ -1,0 +1,130 @@
+"""DecodeCPU of the product ABI (libbrotlig_cpu.so, include/brotlig_amd_cpu.h; reference prototype
+inc/BrotligDecoder.h:33) against the oracle: bit-exact on every case class, on the committed fixtures, on random
+streams, and no out-of-bounds access on damaged ones.  CPU only."""
+import ctypes
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from brotli_g_sdk_amd import _build, cpu
+from brotli_g_sdk_amd import datagen as D
+from brotli_g_sdk_amd import encoder as E
+from cases import plain_cases, precon_cases, raw_stress_cases
+from fuzzcases import corrupt, random_plain, random_precon
+from helpers import ROOT, oracle_decode
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def guarded_decode(stream, cap, workers=None):
+    """Runs the decoder with canaries on both sides of the output and an input buffer that ends exactly at input_size."""
+    s = np.ascontiguousarray(stream, dtype=np.uint8).copy()
+    buf = np.full(cap + 128, 0xC3, np.uint8)
+    osz = ctypes.c_uint32(cap)
+    L = cpu.lib()
+    rc = L.BrotligDecodeCPU(len(s), s.ctypes.data, ctypes.byref(osz), buf[64:].ctypes.data, 0 if workers is None else workers)
+    assert np.all(buf[:64] == 0xC3) and np.all(buf[64 + cap:] == 0xC3), "DecodeCPU wrote outside the output buffer"
+    return rc, buf[64:64 + osz.value].copy()
+
+
+def test_library_exports_the_declared_symbols():
+    so = ctypes.CDLL(_build.build_cpu())
+    for n in ("DecodeCPU", "BrotligDecodeCPU", "DecompressedSize"):
+        assert hasattr(so, n), n
+    # and the GPU library stays GPU-only
+    hip = ctypes.CDLL(_build.build_hip())
+    assert not hasattr(hip, "DecodeCPU") and not hasattr(hip, "BrotligDecodeCPU")
+
+
+def test_gpu_host_code_never_touches_the_cpu_library():
+    for f in ("api.py", "shard.py", os.path.join("csrc", "brotlig_hip.hip"), os.path.join("csrc", "brotlig_streamer.hip")):
+        text = open(os.path.join(ROOT, "brotli_g_sdk_amd", f)).read()
+        assert "brotlig_cpu" not in text and "DecodeCPU(" not in text.replace("DecodeCPU / DecodeGPU", ""), f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "brotlig_cpu" not in bench and "import cpu" not in bench
+
+
+@pytest.mark.parametrize("name,thunk,kw", plain_cases() + raw_stress_cases()[:4], ids=lambda v: v if isinstance(v, str) else "")
+def test_plain_cases_match_the_oracle(name, thunk, kw):
+    data = np.ascontiguousarray(thunk(), dtype=np.uint8)
+    stream = E.encode(data, **kw)
+    rc, ref = oracle_decode(stream)
+    assert rc == 0 and np.array_equal(ref, data)
+    for workers in (1, 3, None):
+        rc, out = guarded_decode(stream, len(data), workers)
+        assert rc == 0 and np.array_equal(out, ref), (name, workers)
+
+
+@pytest.mark.parametrize("name,thunk,pre", precon_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_preconditioned_cases_match_the_oracle(name, thunk, pre):
+    tex = thunk()
+    stream = E.encode(tex, precondition=pre)
+    rc, ref = oracle_decode(stream, out_size=len(tex))
+    assert rc == 0
+    rc, out = guarded_decode(stream, len(tex))
+    assert rc == 0 and np.array_equal(out, ref), name
+
+
+def test_golden_fixtures():
+    index = json.load(open(os.path.join(GOLDEN, "index.json")))
+    assert index
+    for name, meta in index.items():
+        stream = np.fromfile(os.path.join(GOLDEN, name + ".brotlig"), dtype=np.uint8)
+        rc, out = cpu.DecodeCPU(stream, output_size=meta["size"])
+        assert rc == 0 and len(out) == meta["size"], name
+        assert hashlib.sha256(out.tobytes()).hexdigest() == meta["sha256"], name
+
+
+def test_random_streams_match_the_oracle():
+    for seed in range(120):
+        data, kw = random_plain(seed)
+        stream = E.encode(data, **kw)
+        rc, out = guarded_decode(stream, len(data))
+        assert rc == 0 and np.array_equal(out, data), seed
+    for seed in range(60):
+        tex, pre, kw = random_precon(seed)
+        stream = E.encode(tex, precondition=pre, **kw)
+        rc, ref = oracle_decode(stream, out_size=len(tex))
+        rc2, out = guarded_decode(stream, len(tex))
+        assert rc == 0 and rc2 == 0 and np.array_equal(out, ref), seed
+
+
+def test_damaged_streams_fail_or_decode_inside_their_buffers():
+    """Whatever the damage: a return code, no access outside [src, src + input_size) (the copy ends there; run under
+    the guard pages of numpy's allocator this is a smoke check, the canaries around the output are the hard one)."""
+    hits = 0
+    for seed in range(150):
+        if seed % 3:
+            data, kw = random_plain(seed)
+            stream, cap = E.encode(data, **kw), len(data)
+        else:
+            tex, pre, kw = random_precon(seed)
+            stream, cap = E.encode(tex, precondition=pre, **kw), len(tex)
+        bad, kind = corrupt(stream, seed)
+        rc, _ = guarded_decode(bad, cap)
+        hits += rc != 0
+    assert hits > 20
+
+
+def test_error_codes_of_the_header_checks():
+    data = D.text(70000, 1)
+    s = E.encode(data)
+    bad = s.copy(); bad[1] ^= 0x10                                  # magic != id ^ 0xFF: src/BrotligDecoder.cpp:437-441
+    assert guarded_decode(bad, len(data))[0] == 14
+    bad = s.copy(); bad[0] = 6; bad[1] = 6 ^ 0xFF                   # id != 5: :442-446
+    assert guarded_decode(bad, len(data))[0] == 15
+    assert guarded_decode(s, len(data) - 1)[0] == 16                # output too small
+    assert guarded_decode(s[:6], len(data))[0] != 0
+    rc, out = guarded_decode(s, len(data) + 1000)                   # larger capacity: size comes back
+    assert rc == 0 and len(out) == len(data) and np.array_equal(out, data)
+
+
+def test_big_batch_worker_counts_agree():
+    data = D.mixed(40 * 65536 + 17, seed=3)
+    stream = E.encode(data)
+    for workers in (1, 2, 7, 64, None):
+        rc, out = cpu.DecodeCPU(stream, workers=workers)
+        assert rc == 0 and np.array_equal(out, data), workers

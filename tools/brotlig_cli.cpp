@@ -4,13 +4,13 @@
 //   brotlig [Options] filename [outfilename]      compress to filename.brotlig
 //   brotlig [Options] filename.brotlig [out]      decompress to filename (or `out`)
 // Compression calls BrotligEncode (brotli_g_sdk_amd/csrc/brotlig_encoder.h); decompression calls
-// DecodeGPU (include/brotlig_amd.h).  This repo has no CPU decode path: decompression always runs on the
-// GPU (`-gpu` is accepted and redundant, `-warp` is ignored) and fails if no HIP device is usable.
+// DecodeGPU (include/brotlig_amd.h) and fails if no HIP device is usable (`-gpu` is accepted and redundant, `-warp`
+// is ignored); there is no silent fallback.  `-cpu` asks for DecodeCPU (include/brotlig_amd_cpu.h) instead.
 // The stock-Brotli switches of the sample (-brotli ...) are not provided.
 // Reports sizes, milliseconds and throughput like the sample (sample/brotlig_cli.cpp:626-639: source
 // bytes per second in GiB/s), plus the decompressed GB/s for decodes.
 //
-// Build: brotli_g_sdk_amd/_build.py build_cli() -- g++ against libbrotlig_enc.so and libbrotlig_hip.so.
+// Build: brotli_g_sdk_amd/_build.py build_cli() -- g++ against libbrotlig_enc.so, libbrotlig_hip.so and libbrotlig_cpu.so.
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "brotlig_amd.h"
+#include "brotlig_amd_cpu.h"
 #include "brotlig_encoder.h"
 
 namespace {
@@ -29,7 +30,7 @@ struct Options {
     bool precondition = false, swizzle = false, delta = false, pitch_aligned = false;
     uint32_t format = 0, tex_width = 0, tex_height = 0, row_pitch = 0, num_mips = 1;
     uint32_t repeat = 1;
-    bool verbose = false, fast = false;
+    bool verbose = false, fast = false, cpu = false;
     std::string src, dst;
 };
 
@@ -51,6 +52,7 @@ void usage()
            " -texture-pitch-d3d12-aligned  : mip pitches are 256-byte aligned\n"
            " -gpu                          : decompress on the GPU (always the case here)\n"
            " -warp                         : ignored\n"
+           " -cpu                          : decompress with DecodeCPU on the host's threads instead\n"
            " -num-repeat <value>           : repeat the task (default 1)\n"
            " -fast                         : quicker compression (lazy parse, default distance parameters)\n"
            " -verbose                      : print progress\n");
@@ -101,6 +103,7 @@ bool parse(int argc, char** argv, Options& o)
         else if (!strcmp(a, "-num-mip-levels")) { if (!value(i, o.num_mips)) return false; }
         else if (!strcmp(a, "-texture-pitch-d3d12-aligned")) o.pitch_aligned = true;
         else if (!strcmp(a, "-gpu") || !strcmp(a, "-warp")) {}
+        else if (!strcmp(a, "-cpu")) o.cpu = true;
         else if (!strcmp(a, "-num-repeat")) { if (!value(i, o.repeat)) return false; }
         else if (!strcmp(a, "-verbose")) o.verbose = true;
         else if (!strcmp(a, "-fast")) o.fast = true;
@@ -166,16 +169,23 @@ int decompress(const Options& o, std::vector<uint8_t>& src)
         out_size = size;
         double kernel_ms = 0;
         const double t0 = now_ms();
-        const BROTLIG_ERROR rc = DecodeGPU(0, (uint32_t)src.size(), src.data(), &out_size, out.data(), &kernel_ms);
-        wall_total += now_ms() - t0;
-        if (rc != BROTLIG_OK) { fprintf(stderr, "brotlig: DecodeGPU failed with BROTLIG_ERROR %d\n", (int)rc); return 3; }
-        kernel_total += kernel_ms;
+        const BROTLIG_ERROR rc = o.cpu ? DecodeCPU((uint32_t)src.size(), src.data(), &out_size, out.data(), nullptr)
+                                       : DecodeGPU(0, (uint32_t)src.size(), src.data(), &out_size, out.data(), &kernel_ms);
+        const double wall = now_ms() - t0;
+        wall_total += wall;
+        if (rc != BROTLIG_OK) { fprintf(stderr, "brotlig: %s failed with BROTLIG_ERROR %d\n", o.cpu ? "DecodeCPU" : "DecodeGPU", (int)rc); return 3; }
+        kernel_total += o.cpu ? wall : kernel_ms;
         if (o.verbose) printf("  pass %u: kernel %.3f ms\n", r + 1, kernel_ms);
     }
     std::string dst = o.dst;
     if (dst.empty()) dst = o.src.substr(0, o.src.size() - strlen(".brotlig"));
     if (!write_file(dst, out.data(), out_size)) { fprintf(stderr, "brotlig: cannot write %s\n", dst.c_str()); return 4; }
     const double ms = kernel_total / o.repeat;
+    if (o.cpu) {
+        printf("Decompressed %zu -> %u bytes on the CPU: %.3f ms (%.3f GiB/s of source, %.2f GB/s decompressed)  -> %s\n", src.size(), out_size,
+               ms, src.size() / (ms * 1e-3) / (1024.0 * 1024.0 * 1024.0), out_size / (ms * 1e-3) / 1e9, dst.c_str());
+        return 0;
+    }
     printf("Decompressed %zu -> %u bytes on the GPU: kernel %.3f ms (%.3f GiB/s of source, %.2f GB/s decompressed), "
            "call %.3f ms incl. PCIe  -> %s\n", src.size(), out_size, ms, src.size() / (ms * 1e-3) / (1024.0 * 1024.0 * 1024.0),
            out_size / (ms * 1e-3) / 1e9, wall_total / o.repeat, dst.c_str());
