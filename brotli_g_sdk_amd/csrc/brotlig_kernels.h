@@ -79,6 +79,8 @@ struct DecodeArgs {
     uint32_t* order;        // [order_cap] page schedule: global page indices grouped by bucket (null: page order)
     uint32_t  order_cap;
     DcTable*  dc;           // [num_streams]
+    uint16_t* dist_syms;    // [workgroups of the decode grid][2][kDistSymStride] distance symbols in canonical-code order,
+                            // one slot per 32-lane half (the rarely read one of the three such arrays; the other two sit in LDS)
     unsigned long long* prof;   // [kNumPhases] cycle sums, only written by the phase-timer instantiation
 };
 
@@ -165,13 +167,13 @@ struct __attribute__((aligned(16))) PageLds {
                                             // the window before the far sources arrive), then the source bytes of far
                                             // copies (older than the window)
     uint32_t sorted_icp[(kIcpAlphabet + 2) / 3];       // symbols in canonical-code order, three 10-bit fields per word
-    uint32_t sorted_dist[(kDistAlphabet + 2) / 3];
     uint32_t sorted_lit[kLitAlphabet / 4];             // literals fit a byte each: plain byte array
     uint16_t limit[3][16] __attribute__((aligned(16)));     // per code length: exclusive upper bound, left-justified to 15 bits
     uint32_t first_offs[3][16]; // per code length: first code (left-justified) | index of its first symbol in sorted_* << 16
     uint32_t start_bits[kRoundMax / 32];    // per group: bit p set <=> a command's piece starts at group byte p
     uint8_t  start_cum[kRoundMax / 32];     // per group: piece starts in earlier words of start_bits
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
+    uint32_t page_params;           // NPOSTFIX | (NDIRECT << NPOSTFIX) << 8 | delta-coded flag << 16 of the page being decoded
     uint32_t ring_push[2][4] __attribute__((aligned(16)));  // the last four distances pushed in a round, most recent first (two rounds alternate)
     uint8_t  win[kWin + 16] __attribute__((aligned(16)));   // output window; doubles as the code-length
                                                              // scratch (728 B) while tables are built
@@ -417,11 +419,24 @@ __device__ __forceinline__ uint32_t advance_mod(uint32_t r, uint32_t step, uint3
     return r;
 }
 
+constexpr uint32_t kDistSymStride = 576;    // uint16 per half: 544 symbols, padded to a multiple of 128 bytes
 // One prefix-code table: which LDS arrays it lives in.
 struct TableRef {
     uint16_t* lut; uint32_t* sorted; uint16_t* limit; uint32_t* first_offs;
     uint32_t alphabet; int lut_bits;
+    uint16_t* far_syms;         // distance table only: its symbols in canonical-code order live in global memory (`sorted`
+                                // unused): slot of the workgroup's first half; the second half's follows (kDistSymStride)
 };
+
+
+// Offset of this half's slot behind TableRef::far_syms.  Formed where it is used (two instructions) rather than
+// carried in a register through the whole kernel: the reads are rare.
+__device__ __forceinline__ uint32_t far_slot()
+{
+    uint32_t half = wave::lane_id() >> 5;
+    asm volatile("" : "+v"(half));
+    return half * kDistSymStride;
+}
 
 // sorted-symbol arrays: element i lives in bits [10 * (i % 3), +10) of word i / 3
 __device__ __forceinline__ uint32_t sorted_get(const uint32_t* words, uint32_t i)
@@ -437,11 +452,13 @@ __device__ __forceinline__ void sorted_put(uint32_t* words, uint32_t i, uint32_t
 // the literal table (256 symbols) keeps its symbols as bytes instead
 __device__ __forceinline__ uint32_t table_sym(const TableRef& t, uint32_t i)
 {
+    if (t.alphabet == kDistAlphabet) return t.far_syms[far_slot() + i];
     return t.alphabet == kLitAlphabet ? (uint32_t)reinterpret_cast<const uint8_t*>(t.sorted)[i] : sorted_get(t.sorted, i);
 }
 __device__ __forceinline__ void table_set_sym(const TableRef& t, uint32_t i, uint32_t sym)   // packed words pre-zeroed
 {
-    if (t.alphabet == kLitAlphabet) reinterpret_cast<uint8_t*>(t.sorted)[i] = (uint8_t)sym;
+    if (t.alphabet == kDistAlphabet) t.far_syms[far_slot() + i] = (uint16_t)sym;
+    else if (t.alphabet == kLitAlphabet) reinterpret_cast<uint8_t*>(t.sorted)[i] = (uint8_t)sym;
     else sorted_put(t.sorted, i, sym);
 }
 
@@ -576,7 +593,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         const uint32_t blk = (A + 31u) / 32u;
         const uint32_t b0 = sl * blk, b1 = min_u32(A, b0 + blk);
         if (is_complex) for (uint32_t l = 0; l < 16u; ++l) cnt[l * 32u + sl] = 0;
-        if (is_complex && A != kLitAlphabet) for (uint32_t w = sl; w < (A + 2u) / 3u; w += 32u) t.sorted[w] = 0u;
+        if (is_complex && A == kIcpAlphabet) for (uint32_t w = sl; w < (A + 2u) / 3u; w += 32u) t.sorted[w] = 0u;
         wave::sync();
         if (is_complex)
             for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = L.win[s] & 15u; if (l) cnt[l * 32u + sl]++; }
@@ -600,7 +617,9 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
                 const uint32_t l = L.win[s] & 15u;
                 if (l) { const uint32_t p = cnt[l * 32u + sl]++; table_set_sym(t, min_u32(p, A - 1u), s); }
             }
-        wave::sync();
+        // the distance symbols went to global memory: stores first, then the reads below and in the rounds (same CU,
+        // same L1: workgroup scope is enough)
+        if (A == kDistAlphabet) wave::global_fence(); else wave::sync();
         // primary LUT, one entry per lane per step
         if (is_complex) {
             uint32_t lim[8];                                       // limits of lengths 0..15, two per word
@@ -755,17 +774,16 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
     PageLds& L = W.page[lane >> 5];
 
     // the three prefix codes of a page: ICP, distance, literal (PageDecoder.cpp:125-147)
-    const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first_offs[0], kIcpAlphabet, kLutBitsIcp};
-    const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist};
-    const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit};
+    uint16_t* const far_syms = a.dist_syms + (size_t)blockIdx.x * (2u * kDistSymStride);
+    const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first_offs[0], kIcpAlphabet, kLutBitsIcp, nullptr};
+    const TableRef t_dist{L.lut_dist, nullptr, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist, far_syms};
+    const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit, nullptr};
 
     const uint32_t resync_quarters = a.status[3];                       // pairing policy, set by the prepare kernel
     // ---- per-half state of the page under construction
     PageJob job = fetch_job(a, nullptr, 0u, false);
     bool live = false;               // inside a compressed page
     bool finished = false;           // the work counter ran out for this half
-    uint32_t npostfix = 0, ndirect = 0;
-    bool is_delta = false;
     BitReader br;
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
     uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16;             // PageDecoder.cpp:150-153
@@ -773,7 +791,6 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
     uint32_t out_pos = 0;            // bytes of the page produced so far
     uint32_t prev_tail = 0;          // literals decoded but not yet consumed
     uint32_t carry_head = 0;
-    uint32_t rounds_left = 0;
     bool bad = false;
     OutView view{L.win, 0u};
     uint32_t flushed = 0;            // page bytes below this are in global memory
@@ -825,9 +842,10 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                     if (start) {
                         const uint32_t w0 = br_load(job, 0u), w1 = br_load(job, 4u);
                         const uint64_t h = (uint64_t)w0 | ((uint64_t)w1 << 32);
-                        npostfix = (uint32_t)h & 3u;
-                        ndirect = (((uint32_t)h >> 2) & 15u) << npostfix;
-                        is_delta = (((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr;       // PageDecoder.cpp:87-88
+                        const uint32_t npostfix = (uint32_t)h & 3u;
+                        const uint32_t is_delta = ((((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr) ? 1u : 0u;   // PageDecoder.cpp:87-88
+                        // kept in LDS rather than in a register for the whole page: read once per round at most
+                        if (sl == 0u) L.page_params = npostfix | ((((uint32_t)h >> 2) & 15u) << (npostfix + 8u)) | (is_delta << 16);
                         const uint32_t base_bits = bit_width_u32((job.in_size + 31u) / 32u);
                         const uint32_t dsize_bits = bit_width_u32(bit_width_u32(job.in_size - 1u));
                         const uint32_t base_size = (uint32_t)(h >> 8) & ((1u << base_bits) - 1u);
@@ -849,16 +867,15 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
 #pragma nounroll
                 for (uint32_t k = 0; k < 3u; ++k) {
                     const TableRef t{k == 0u ? L.lut_icp : k == 1u ? L.lut_dist : L.lut_lit,
-                                     k == 0u ? L.sorted_icp : k == 1u ? L.sorted_dist : L.sorted_lit,
+                                     k == 0u ? L.sorted_icp : L.sorted_lit,
                                      L.limit[k], L.first_offs[k],
                                      k == 0u ? kIcpAlphabet : k == 1u ? kDistAlphabet : kLitAlphabet,
-                                     k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit};
+                                     k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit, far_syms};
                     build_table(t, L, br, start, sl);
                 }
                 if (start) {
                     ring0 = 4; ring1 = 11; ring2 = 15; ring3 = 16; ring_cnt = 0;
                     out_pos = 0; prev_tail = 0; carry_head = 0; flushed = 0; bad = false;
-                    rounds_left = job.page_size / 64u + 4u;             // every full round emits >= 64 bytes
                     view.win_base = 0u;
                     live = true;
                 }
@@ -909,6 +926,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
                 dcode = decode_symbol<kLutBitsDist>(t_dist, br, dl);
                 br.consume(dl);
                 if (dcode >= 16u) {                                     // PageDecoder.cpp:365-390
+                    const uint32_t pp = L.page_params;
+                    const uint32_t npostfix = pp & 3u, ndirect = (pp >> 8) & 0xFFu;
                     if (dcode < 16u + ndirect) dist = dcode - 15u;
                     else {
                         const uint32_t x = dcode - ndirect - 16u;
@@ -988,10 +1007,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
         const uint32_t litcount = wave::half_bcast(incl_ins, 31);
         const uint32_t cmd_out = out_pos + incl_tot - tot;              // first literal of my command
         const uint32_t copy_dst = cmd_out + ins;
-        if (live) {
-            --rounds_left;
-            if (round_bytes > job.out_size - out_pos || rounds_left == 0u) { bad = true; live = false; }
-        }
+        // (every command emits at least one byte, so a page of full rounds ends here after out_size / 32 rounds at most)
+        if (live && round_bytes > job.out_size - out_pos) { bad = true; live = false; }
         const bool ok_cmd = is_cmd && live;
 
         // literal bookkeeping of the round (PageDecoder.cpp:196-199)
@@ -1394,7 +1411,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
 
     // ---- per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): a running byte
     //      sum over each colour range inside the page.
-    const bool do_delta = ended && is_delta && !bad;
+    const bool do_delta = ended && (L.page_params >> 16) != 0u && !bad;
     if (wave::any(do_delta)) {
         wave::global_fence();
         for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
@@ -1773,9 +1790,9 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
     decode_pages<kProf>(W, a);
 }
 
-__global__ void __launch_bounds__(64, 3) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }
+__global__ void __launch_bounds__(64, 4) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }
 // Diagnostics twin: same code with s_memtime phase timers (BrotligDecodePhaseProfile).
-__global__ void __launch_bounds__(64, 3) brotlig_decode_kernel_timed(DecodeArgs a) { decode_kernel_body<true>(a); }
+__global__ void __launch_bounds__(64, 4) brotlig_decode_kernel_timed(DecodeArgs a) { decode_kernel_body<true>(a); }
 
 // Device self-test of the cross-lane primitives (results checked on the host).
 __global__ void __launch_bounds__(64) brotlig_selftest_kernel(uint32_t* out)
