@@ -119,7 +119,7 @@ constexpr uint32_t kAblate = BROTLIG_ABLATE;
 
 // ---- tunables ---------------------------------------------------------------------------
 constexpr int kLutBitsIcp = 8;
-constexpr int kLutBitsDist = 8;
+constexpr int kLutBitsDist = 7;
 constexpr int kLutBitsLit = 8;
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
@@ -129,7 +129,7 @@ constexpr uint32_t kOwnCopy = 128;          // simple copies up to this length r
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
 // flushed to global memory in aligned 16-byte stores when it slides.
-constexpr uint32_t kWin = 1536;
+constexpr uint32_t kWin = 1248;
 constexpr uint32_t kHist = 528;             // history kept across a slide (>= kRoundMax + 16: see the slide below)
 constexpr uint32_t kRoundMax = 512;          // bytes assembled per group
 static_assert(kHist >= kRoundMax + 16u && kWin >= kHist + 16u + kRoundMax, "window: history + one group");
@@ -179,8 +179,8 @@ struct __attribute__((aligned(16))) PageLds {
                                                              // scratch (728 B) while tables are built
 };
 constexpr uint32_t kTableScratchBytes = 1024;   // 512-entry code-length LUT, or 16 x 32 counters, as uint16
-static_assert(sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist)) >= kTableScratchBytes, "ICP build scratch");
-static_assert(sizeof(uint16_t) * ((1 << kLutBitsDist) + (1 << kLutBitsLit)) >= kTableScratchBytes, "distance build scratch");
+static_assert(sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)) >= kTableScratchBytes, "ICP build scratch");
+static_assert(sizeof(uint16_t) * ((1 << kLutBitsDist) + (1 << kLutBitsLit)) + kStageBytes >= kTableScratchBytes, "distance build scratch");
 static_assert(sizeof(uint16_t) * (1 << kLutBitsLit) + kStageBytes >= kTableScratchBytes, "literal build scratch");
 static_assert(__builtin_offsetof(PageLds, lut_dist) == sizeof(uint16_t) * (1 << kLutBitsIcp), "LUTs must be contiguous");
 static_assert(__builtin_offsetof(PageLds, stage) == sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)), "staging area must follow the LUTs");
@@ -433,9 +433,7 @@ struct TableRef {
 // carried in a register through the whole kernel: the reads are rare.
 __device__ __forceinline__ uint32_t far_slot()
 {
-    uint32_t half = wave::lane_id() >> 5;
-    asm volatile("" : "+v"(half));
-    return half * kDistSymStride;
+    return (wave::lane_id_fresh() >> 5) * kDistSymStride;
 }
 
 // sorted-symbol arrays: element i lives in bits [10 * (i % 3), +10) of word i / 3

@@ -13,6 +13,13 @@
 namespace wave {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// the same from the execution mask (two instructions), for rare paths that should not keep a register alive for it
+__device__ __forceinline__ uint32_t lane_id_fresh()
+{
+    uint32_t lane;      // (volatile: computed where it stands, never hoisted and carried)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return lane;
+}
 
 // ---- wave scope -------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }

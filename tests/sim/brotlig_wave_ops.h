@@ -7,6 +7,7 @@
 namespace wave {
 
 inline uint32_t lane_id() { return sim::lane_now() & 63u; }
+inline uint32_t lane_id_fresh() { return lane_id(); }
 
 #define SIM_SITE int site = __builtin_LINE()
 
