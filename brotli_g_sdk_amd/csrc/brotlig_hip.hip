@@ -30,11 +30,11 @@ static_assert(sizeof(BrotligStreamDesc) == sizeof(StreamDesc), "descriptor layou
 // workspace has the room -- the page schedule (one word per page).
 constexpr size_t kWsHeaderWords = 64;
 size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 1023u) & ~(size_t)1023u; }
-// per-half slots for the distance symbols of the page being decoded, one per workgroup of the largest decode grid
+// per-half slots for the prefix-code symbols that overflow the LDS arrays, for every workgroup of the largest decode grid
 constexpr uint32_t kMaxDecodeGrid = 4096;
-constexpr size_t kDistSymBytes = (size_t)kMaxDecodeGrid * 2u * kDistSymStride * sizeof(uint16_t);
-size_t dist_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
-size_t workspace_bytes(uint32_t n) { return dist_syms_offset(n) + kDistSymBytes; }
+constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
+size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
+size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
 // every page is at least 32 KiB of output, and every stream's output region is whole pages
 uint64_t max_pages(uint32_t n, uint64_t out_bytes) { return out_bytes / kMinPageSize + n; }
 // Below this many pages the schedule is not worth its two extra launches (about two pages per half-wave).
@@ -95,7 +95,7 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
     a.streams = reinterpret_cast<const StreamDesc*>(d_streams); a.num_streams = n;
     a.status = ws; a.work_counter = ws + 1; a.page_base = ws + kWsHeaderWords;
     a.dc = reinterpret_cast<DcTable*>(static_cast<uint8_t*>(d_ws) + dc_offset(n));
-    a.dist_syms = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_ws) + dist_syms_offset(n));
+    a.far_syms = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_ws) + far_syms_offset(n));
     const size_t base = workspace_bytes(n);
     const uint64_t room = ws_bytes > base ? (ws_bytes - base) / 4u : 0u;
     if (out_bytes >= kOrderMinOutBytes && room >= max_pages(n, out_bytes)) {

@@ -79,8 +79,8 @@ struct DecodeArgs {
     uint32_t* order;        // [order_cap] page schedule: global page indices grouped by bucket (null: page order)
     uint32_t  order_cap;
     DcTable*  dc;           // [num_streams]
-    uint16_t* dist_syms;    // [workgroups of the decode grid][2][kDistSymStride] distance symbols in canonical-code order,
-                            // one slot per 32-lane half (the rarely read one of the three such arrays; the other two sit in LDS)
+    uint16_t* far_syms;     // [workgroups of the decode grid][2][kFarSymStride] per 32-lane half: the ICP and distance symbols
+                            // (canonical-code order) that do not fit the LDS arrays -- ranks kIcpSymCap.. and kDistSymCap..
     unsigned long long* prof;   // [kNumPhases] cycle sums, only written by the phase-timer instantiation
 };
 
@@ -90,20 +90,35 @@ enum : int { kPhSetup, kPhTables, kPhCommands, kPhRing, kPhPositions, kPhLiteral
              kPhCmdSym, kPhCmdExtra, kPhSlide, kPhPieces, kPhBitmaps, kPhGroups, kPhLitSteps, kPhLvOverlap, kPhTeamLevels, kNumPhases };
 template <bool kOn> struct PhaseClock;
 template <> struct PhaseClock<false> {
-    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void start(unsigned long long*) {}
     __device__ __forceinline__ void lap(int) {}
     __device__ __forceinline__ void count(int, uint32_t) {}
     __device__ __forceinline__ void flush(unsigned long long*, uint32_t) {}
 };
+// The sums live in LDS (lane 0 adds to them): fifty registers of accumulators would push the kernel's own state
+// into scratch memory and time that instead.
 template <> struct PhaseClock<true> {
-    unsigned long long t0, last, acc[kNumPhases];
-    __device__ __forceinline__ void start() { for (int i = 0; i < kNumPhases; ++i) acc[i] = 0; t0 = last = wave::clock(); }
-    __device__ __forceinline__ void lap(int ph) { const unsigned long long t = wave::clock(); acc[ph] += t - last; last = t; }
-    __device__ __forceinline__ void count(int ph, uint32_t n) { acc[ph] += n; }
+    unsigned long long t0, last;
+    unsigned long long* acc;        // [kNumPhases] in LDS
+    __device__ __forceinline__ void start(unsigned long long* lds)
+    {
+        acc = lds;
+        if (wave::lane_id() < (uint32_t)kNumPhases) acc[wave::lane_id()] = 0;
+        wave::sync();
+        t0 = last = wave::clock();
+    }
+    __device__ __forceinline__ void lap(int ph)
+    {
+        const unsigned long long t = wave::clock();
+        if (wave::lane_id() == 0u) acc[ph] += t - last;
+        last = t;
+    }
+    __device__ __forceinline__ void count(int ph, uint32_t n) { if (wave::lane_id() == 0u) acc[ph] += n; }
     __device__ __forceinline__ void flush(unsigned long long* out, uint32_t lane)
     {
-        acc[kPhTotal] = wave::clock() - t0;
-        if (lane == 0u && out) for (int i = 0; i < kNumPhases; ++i) atomicAdd(out + i, acc[i]);
+        if (lane == 0u) acc[kPhTotal] = wave::clock() - t0;
+        wave::sync();
+        if (lane < (uint32_t)kNumPhases && out) atomicAdd(out + lane, acc[lane]);
     }
 };
 
@@ -119,8 +134,20 @@ constexpr uint32_t kAblate = BROTLIG_ABLATE;
 
 // ---- tunables ---------------------------------------------------------------------------
 constexpr int kLutBitsIcp = 8;
-constexpr int kLutBitsDist = 7;
+constexpr int kLutBitsDist = 8;
 constexpr int kLutBitsLit = 8;
+// Symbols in canonical-code order ("sorted" arrays, read for codes longer than the LUT index): LDS holds the first
+// kIcpSymCap / kDistSymCap of them, global memory (DecodeArgs::far_syms) the rest.  Pages of the benchmark's data
+// classes use at most 146 ICP symbols (mean 81) and 40 distance symbols (115 under the encoder's distance-parameter
+// search), so the overflow is for odd pages only (tests/cases.py: many_command_shapes, many_distances).
+#ifndef BROTLIG_ICP_SYM_CAP
+#define BROTLIG_ICP_SYM_CAP 255
+#define BROTLIG_DIST_SYM_CAP 96
+#endif
+constexpr uint32_t kIcpSymCap = BROTLIG_ICP_SYM_CAP;      // multiples of 3 fill whole words (three 10-bit fields each)
+constexpr uint32_t kDistSymCap = BROTLIG_DIST_SYM_CAP;
+constexpr uint32_t kFarIcp = kIcpAlphabet - kIcpSymCap, kFarDist = kDistAlphabet - kDistSymCap;
+constexpr uint32_t kFarSymStride = (kFarIcp + kFarDist + 63u) & ~63u;   // uint16 per half: ICP overflow, then distance overflow
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
 constexpr uint32_t kShortCopy = 32;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
@@ -129,7 +156,7 @@ constexpr uint32_t kOwnCopy = 128;          // simple copies up to this length r
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
 // flushed to global memory in aligned 16-byte stores when it slides.
-constexpr uint32_t kWin = 1248;
+constexpr uint32_t kWin = 1488;
 constexpr uint32_t kHist = 528;             // history kept across a slide (>= kRoundMax + 16: see the slide below)
 constexpr uint32_t kRoundMax = 512;          // bytes assembled per group
 static_assert(kHist >= kRoundMax + 16u && kWin >= kHist + 16u + kRoundMax, "window: history + one group");
@@ -166,7 +193,8 @@ struct __attribute__((aligned(16))) PageLds {
     uint64_t stage[kStageBytes / 8];        // per group: first the group's literals in consumption order (they move to
                                             // the window before the far sources arrive), then the source bytes of far
                                             // copies (older than the window)
-    uint32_t sorted_icp[(kIcpAlphabet + 2) / 3];       // symbols in canonical-code order, three 10-bit fields per word
+    uint32_t sorted_icp[(kIcpSymCap + 2) / 3];         // symbols in canonical-code order, three 10-bit fields per word
+    uint32_t sorted_dist[(kDistSymCap + 2) / 3];
     uint32_t sorted_lit[kLitAlphabet / 4];             // literals fit a byte each: plain byte array
     uint16_t limit[3][16] __attribute__((aligned(16)));     // per code length: exclusive upper bound, left-justified to 15 bits
     uint32_t first_offs[3][16]; // per code length: first code (left-justified) | index of its first symbol in sorted_* << 16
@@ -419,21 +447,23 @@ __device__ __forceinline__ uint32_t advance_mod(uint32_t r, uint32_t step, uint3
     return r;
 }
 
-constexpr uint32_t kDistSymStride = 576;    // uint16 per half: 544 symbols, padded to a multiple of 128 bytes
 // One prefix-code table: which LDS arrays it lives in.
 struct TableRef {
     uint16_t* lut; uint32_t* sorted; uint16_t* limit; uint32_t* first_offs;
     uint32_t alphabet; int lut_bits;
-    uint16_t* far_syms;         // distance table only: its symbols in canonical-code order live in global memory (`sorted`
-                                // unused): slot of the workgroup's first half; the second half's follows (kDistSymStride)
+    uint16_t* far_syms;         // global overflow of `sorted` (ICP and distance tables): slot of the workgroup's first half; the
+                                // second half's follows (kFarSymStride)
 };
-
-
-// Offset of this half's slot behind TableRef::far_syms.  Formed where it is used (two instructions) rather than
-// carried in a register through the whole kernel: the reads are rare.
-__device__ __forceinline__ uint32_t far_slot()
+// symbols of canonical rank >= cap live in global memory, at far_syms[far_slot(alphabet) + rank - cap]
+__device__ __forceinline__ uint32_t sym_cap(uint32_t alphabet)
 {
-    return (wave::lane_id_fresh() >> 5) * kDistSymStride;
+    return alphabet == kIcpAlphabet ? kIcpSymCap : alphabet == kDistAlphabet ? kDistSymCap : kLitAlphabet;
+}
+// Offset of this half's slot behind TableRef::far_syms.  Formed where it is used (a few instructions) rather than
+// carried in a register through the whole kernel: the reads are rare.
+__device__ __forceinline__ uint32_t far_slot(uint32_t alphabet)
+{
+    return (wave::lane_id_fresh() >> 5) * kFarSymStride + (alphabet == kDistAlphabet ? kFarIcp : 0u);
 }
 
 // sorted-symbol arrays: element i lives in bits [10 * (i % 3), +10) of word i / 3
@@ -450,14 +480,17 @@ __device__ __forceinline__ void sorted_put(uint32_t* words, uint32_t i, uint32_t
 // the literal table (256 symbols) keeps its symbols as bytes instead
 __device__ __forceinline__ uint32_t table_sym(const TableRef& t, uint32_t i)
 {
-    if (t.alphabet == kDistAlphabet) return t.far_syms[far_slot() + i];
-    return t.alphabet == kLitAlphabet ? (uint32_t)reinterpret_cast<const uint8_t*>(t.sorted)[i] : sorted_get(t.sorted, i);
+    if (t.alphabet == kLitAlphabet) return (uint32_t)reinterpret_cast<const uint8_t*>(t.sorted)[i];
+    const uint32_t cap = sym_cap(t.alphabet);
+    if (i < cap) return sorted_get(t.sorted, i);
+    return (uint32_t)t.far_syms[far_slot(t.alphabet) + (i - cap)] & 0x3FFu;     // (same value range as the packed fields)
 }
 __device__ __forceinline__ void table_set_sym(const TableRef& t, uint32_t i, uint32_t sym)   // packed words pre-zeroed
 {
-    if (t.alphabet == kDistAlphabet) t.far_syms[far_slot() + i] = (uint16_t)sym;
-    else if (t.alphabet == kLitAlphabet) reinterpret_cast<uint8_t*>(t.sorted)[i] = (uint8_t)sym;
-    else sorted_put(t.sorted, i, sym);
+    if (t.alphabet == kLitAlphabet) { reinterpret_cast<uint8_t*>(t.sorted)[i] = (uint8_t)sym; return; }
+    const uint32_t cap = sym_cap(t.alphabet);
+    if (i < cap) sorted_put(t.sorted, i, sym);
+    else t.far_syms[far_slot(t.alphabet) + (i - cap)] = (uint16_t)sym;
 }
 
 // Decode one symbol from `br` (needs avail >= 15 on entry).  Returns symbol, sets len.
@@ -591,7 +624,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         const uint32_t blk = (A + 31u) / 32u;
         const uint32_t b0 = sl * blk, b1 = min_u32(A, b0 + blk);
         if (is_complex) for (uint32_t l = 0; l < 16u; ++l) cnt[l * 32u + sl] = 0;
-        if (is_complex && A == kIcpAlphabet) for (uint32_t w = sl; w < (A + 2u) / 3u; w += 32u) t.sorted[w] = 0u;
+        if (is_complex && A != kLitAlphabet) for (uint32_t w = sl; w < (sym_cap(A) + 2u) / 3u; w += 32u) t.sorted[w] = 0u;
         wave::sync();
         if (is_complex)
             for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = L.win[s] & 15u; if (l) cnt[l * 32u + sl]++; }
@@ -615,9 +648,9 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
                 const uint32_t l = L.win[s] & 15u;
                 if (l) { const uint32_t p = cnt[l * 32u + sl]++; table_set_sym(t, min_u32(p, A - 1u), s); }
             }
-        // the distance symbols went to global memory: stores first, then the reads below and in the rounds (same CU,
-        // same L1: workgroup scope is enough)
-        if (A == kDistAlphabet) wave::global_fence(); else wave::sync();
+        // symbols beyond the LDS arrays went to global memory: stores first, then the reads below and in the rounds
+        // (same CU, same L1: workgroup scope is enough)
+        if (A != kLitAlphabet) wave::global_fence(); else wave::sync();
         // primary LUT, one entry per lane per step
         if (is_complex) {
             uint32_t lim[8];                                       // limits of lengths 0..15, two per word
@@ -763,18 +796,18 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
 // halves inside a page) + (page end for the halves whose page just finished), each under per-half
 // predicates.
 template <bool kProf>
-__device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
+__device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned long long* prof_lds)
 {
     PhaseClock<kProf> clk;
-    clk.start();
+    clk.start(prof_lds);
     const uint32_t lane = wave::lane_id();
     const uint32_t sl = lane & 31u;
     PageLds& L = W.page[lane >> 5];
 
     // the three prefix codes of a page: ICP, distance, literal (PageDecoder.cpp:125-147)
-    uint16_t* const far_syms = a.dist_syms + (size_t)blockIdx.x * (2u * kDistSymStride);
-    const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first_offs[0], kIcpAlphabet, kLutBitsIcp, nullptr};
-    const TableRef t_dist{L.lut_dist, nullptr, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist, far_syms};
+    uint16_t* const far_syms = a.far_syms + (size_t)blockIdx.x * (2u * kFarSymStride);
+    const TableRef t_icp{L.lut_icp, L.sorted_icp, L.limit[0], L.first_offs[0], kIcpAlphabet, kLutBitsIcp, far_syms};
+    const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist, far_syms};
     const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit, nullptr};
 
     const uint32_t resync_quarters = a.status[3];                       // pairing policy, set by the prepare kernel
@@ -865,7 +898,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a)
 #pragma nounroll
                 for (uint32_t k = 0; k < 3u; ++k) {
                     const TableRef t{k == 0u ? L.lut_icp : k == 1u ? L.lut_dist : L.lut_lit,
-                                     k == 0u ? L.sorted_icp : L.sorted_lit,
+                                     k == 0u ? L.sorted_icp : k == 1u ? L.sorted_dist : L.sorted_lit,
                                      L.limit[k], L.first_offs[k],
                                      k == 0u ? kIcpAlphabet : k == 1u ? kDistAlphabet : kLitAlphabet,
                                      k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit, far_syms};
@@ -1785,7 +1818,12 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
     const uint32_t lane = wave::lane_id();
     if (lane < 48u) W.len_code_tab[lane] = kLenCodeTab[lane];
     wave::sync();
-    decode_pages<kProf>(W, a);
+    unsigned long long* prof_lds = nullptr;
+    if constexpr (kProf) {                  // 200 more bytes of LDS: the timed twin runs 14 workgroups per CU, not 16
+        __shared__ unsigned long long prof_acc[kNumPhases];
+        prof_lds = prof_acc;
+    }
+    decode_pages<kProf>(W, a, prof_lds);
 }
 
 __global__ void __launch_bounds__(64, 4) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }

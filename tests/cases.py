@@ -95,3 +95,50 @@ def raw_stress_cases():
                         (lambda a=dlo, b=dhi, l=lit, c=cpy, s=k: far_boundary(4 * 131072 + 777, 40 + s, a, b, l, c)),
                         dict(page_size=page)))
     return out
+
+
+def many_command_shapes(n, seed):
+    """Literal runs and copies whose lengths are spread log-uniformly over 0..200 and 2..600: about 300 distinct
+    insert-and-copy symbols in a 128 KiB page (the benchmark's data classes use ~150 at most), more than the decoder
+    keeps in LDS (kIcpSymCap = 255) -- the rest of the code's symbols are read from global memory."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(n + 4096, np.uint8)
+    out[:3000] = rng.integers(0, 256, 3000, dtype=np.uint8)
+    pos = 3000
+    while pos < n:
+        lit = int(np.exp(rng.uniform(0, np.log(200)))) - 1
+        out[pos:pos + lit] = rng.integers(0, 256, lit, dtype=np.uint8)
+        pos += lit
+        cpy = min(int(np.exp(rng.uniform(np.log(2), np.log(600)))), 600)
+        d = int(rng.integers(cpy, min(pos, 60000))) if pos > cpy + 1 else pos
+        out[pos:pos + cpy] = out[pos - d:pos - d + cpy]
+        pos += cpy
+    return out[:n].copy()
+
+
+def many_distances(n, seed):
+    """Short copies from distances spread over 10..400 and beyond: with NPOSTFIX 3 / NDIRECT 120 a page uses ~300
+    distinct distance symbols, three times what the decoder keeps in LDS (kDistSymCap = 96)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(n + 64, np.uint8)
+    out[:3000] = rng.integers(0, 256, 3000, dtype=np.uint8)
+    pos = 3000
+    while pos < n:
+        lit = int(rng.integers(1, 6))
+        out[pos:pos + lit] = rng.integers(0, 256, lit, dtype=np.uint8)
+        pos += lit
+        cpy = int(rng.integers(4, 10))
+        d = int(rng.integers(10, 400)) if rng.integers(0, 4) else int(np.exp(rng.uniform(np.log(400), np.log(60000))))
+        d = min(d, pos)
+        out[pos:pos + cpy] = out[pos - d:pos - d + cpy]
+        pos += cpy
+    return out[:n].copy()
+
+
+def symbol_overflow_cases():
+    """Pages whose ICP / distance codes have more symbols than the decoder's LDS arrays hold."""
+    return [
+        ("many_command_shapes_128k", lambda: many_command_shapes(3 * 131072 + 100, 5), dict(page_size=131072)),
+        ("many_distances_np3", lambda: many_distances(3 * 65536 + 100, 6), dict(npostfix=3, ndirect_m=15)),
+        ("many_distances_np2_32k", lambda: many_distances(3 * 32768 + 100, 7), dict(npostfix=2, ndirect_m=15, page_size=32768)),
+    ]

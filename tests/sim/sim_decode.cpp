@@ -40,8 +40,8 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     std::vector<uint32_t> order(g_use_order ? (size_t)(out_bytes / 32768 + num_streams + 1) : 0);
     if (g_use_order) { a.order = order.data(); a.order_cap = (uint32_t)order.size(); }
     const int decode_grid = grid ? grid : 4;
-    std::vector<uint16_t> dist_syms((size_t)decode_grid * 2u * kDistSymStride, 0xFFFFu);     // stale garbage between pages, as on the device
-    a.dist_syms = dist_syms.data();
+    std::vector<uint16_t> far_syms((size_t)decode_grid * 2u * kFarSymStride, 0xFFFFu);     // stale garbage between pages, as on the device
+    a.far_syms = far_syms.data();
     sim::run_grid(1, prepare_body, &a);
     if (a.order) { sim::run_grid(3, order_count_body, &a); sim::run_grid(3, order_scatter_body, &a); }
     sim::run_grid(1, policy_body, &a);

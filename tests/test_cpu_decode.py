@@ -12,7 +12,7 @@ import pytest
 from brotli_g_sdk_amd import _build, cpu
 from brotli_g_sdk_amd import datagen as D
 from brotli_g_sdk_amd import encoder as E
-from cases import plain_cases, precon_cases, raw_stress_cases
+from cases import plain_cases, precon_cases, raw_stress_cases, symbol_overflow_cases
 from fuzzcases import corrupt, random_plain, random_precon
 from helpers import ROOT, oracle_decode
 
@@ -47,7 +47,7 @@ def test_gpu_host_code_never_touches_the_cpu_library():
     assert "brotlig_cpu" not in bench and "import cpu" not in bench
 
 
-@pytest.mark.parametrize("name,thunk,kw", plain_cases() + raw_stress_cases()[:4], ids=lambda v: v if isinstance(v, str) else "")
+@pytest.mark.parametrize("name,thunk,kw", plain_cases() + raw_stress_cases()[:4] + symbol_overflow_cases(), ids=lambda v: v if isinstance(v, str) else "")
 def test_plain_cases_match_the_oracle(name, thunk, kw):
     data = np.ascontiguousarray(thunk(), dtype=np.uint8)
     stream = E.encode(data, **kw)

@@ -9,7 +9,7 @@ import pytest
 
 from brotli_g_sdk_amd import datagen as D
 from brotli_g_sdk_amd import encoder as E
-from cases import plain_cases, precon_cases, raw_stress_cases
+from cases import plain_cases, precon_cases, raw_stress_cases, symbol_overflow_cases
 from helpers import oracle_decode
 
 pytestmark = pytest.mark.gpu
@@ -66,6 +66,24 @@ def test_far_copies_read_what_the_previous_group_flushed(api, name, thunk, kw):
         dec.poison_output()
         dec.decode()
         for i in range(4):
+            assert np.array_equal(dec.output(i), ref), (name, i)
+
+
+@pytest.mark.parametrize("name,thunk,kw", symbol_overflow_cases(), ids=[c[0] for c in symbol_overflow_cases()])
+def test_prefix_codes_with_more_symbols_than_the_lds_arrays_hold(api, name, thunk, kw):
+    """~300 distinct ICP or distance symbols in a page: the decoder keeps the first 255 / 96 (canonical order) in LDS
+    and reads the rest from its workspace.  Several copies side by side, decoded twice: the global slots are reused
+    page after page and must never serve a previous page's symbols."""
+    data = thunk()
+    stream = E.encode(data, **kw)
+    rc, ref = oracle_decode(stream)
+    assert rc == 0 and np.array_equal(ref, data)
+    other = E.encode(D.text(3 * 65536, 77))
+    dec = api.BatchDecoder([stream, other, stream, other, stream])
+    for _ in range(2):
+        dec.poison_output()
+        dec.decode()
+        for i in (0, 2, 4):
             assert np.array_equal(dec.output(i), ref), (name, i)
 
 

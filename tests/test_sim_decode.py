@@ -11,27 +11,38 @@ import pytest
 
 from brotli_g_sdk_amd import datagen as D
 from brotli_g_sdk_amd import encoder as E
-from cases import plain_cases, precon_cases, raw_stress_cases
+from cases import plain_cases, precon_cases, raw_stress_cases, symbol_overflow_cases
 from helpers import ROOT, oracle_decode
 
 SIM_DIR = os.path.join(ROOT, "tests", "sim")
 CSRC = os.path.join(ROOT, "brotli_g_sdk_amd", "csrc")
 
 
-@pytest.fixture(scope="module")
-def sim():
-    so = os.path.join(SIM_DIR, "libbrotlig_sim.so")
+def build_sim(name, flags=()):
+    so = os.path.join(SIM_DIR, name)
     srcs = [os.path.join(SIM_DIR, f) for f in ("sim_decode.cpp", "sim_runtime.cpp")]
     deps = srcs + [os.path.join(SIM_DIR, f) for f in ("sim_runtime.h", "brotlig_wave_ops.h")] + \
         [os.path.join(CSRC, f) for f in ("brotlig_kernels.h", "brotlig_format.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-I", SIM_DIR, "-I", CSRC, "-o", so] + srcs)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-I", SIM_DIR, "-I", CSRC, "-o", so] + list(flags) + srcs)
     L = ctypes.CDLL(so)
     L.sim_decode_batch.restype = ctypes.c_int
     L.sim_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     L.sim_selftest.argtypes = [ctypes.c_void_p]
     return L
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return build_sim("libbrotlig_sim.so")
+
+
+@pytest.fixture(scope="module")
+def sim_small_caps():
+    """The same kernel source with room for 24 ICP and 9 distance symbols in LDS: every page sends the rest of its
+    symbols through the global-memory overflow."""
+    return build_sim("libbrotlig_sim_smallcaps.so", ["-DBROTLIG_ICP_SYM_CAP=24", "-DBROTLIG_DIST_SYM_CAP=9"])
 
 
 def run_batch(sim, streams, sizes, precon=False):
@@ -158,3 +169,30 @@ def test_sim_far_boundary(sim, name, thunk, kw):
     assert rc == 0 and np.array_equal(ref, data)
     outs, status = run_batch(sim, [stream], [len(data)])
     assert status == 0 and np.array_equal(outs[0], ref)
+
+
+@pytest.mark.parametrize("name,thunk,kw", symbol_overflow_cases(), ids=[c[0] for c in symbol_overflow_cases()])
+def test_sim_symbol_overflow(sim, name, thunk, kw):
+    """More ICP / distance symbols in a page than the LDS arrays hold (product caps)."""
+    data = thunk()
+    stream = E.encode(data, **kw)
+    rc, ref = oracle_decode(stream)
+    assert rc == 0 and np.array_equal(ref, data)
+    outs, status = run_batch(sim, [stream], [len(data)])
+    assert status == 0 and np.array_equal(outs[0], ref)
+
+
+def test_sim_small_caps_every_page_overflows(sim_small_caps):
+    picks = [c for c in plain_cases() if c[0] in ("text", "mixed", "records_npostfix3", "skewed_long_codes", "mixed_128k_pages", "samples16")]
+    streams, sizes, refs = [], [], []
+    for name, thunk, kw in picks + symbol_overflow_cases()[:2]:
+        data = thunk()
+        streams.append(E.encode(data, **kw)); sizes.append(len(data)); refs.append(data)
+    outs, status = run_batch(sim_small_caps, streams, sizes)
+    assert status == 0
+    for o, r in zip(outs, refs):
+        assert np.array_equal(o, r)
+    tex_name, tex_thunk, pre = precon_cases()[2]
+    tex = tex_thunk()
+    outs, status = run_batch(sim_small_caps, [E.encode(tex, precondition=pre)], [len(tex)], precon=True)
+    assert status == 0 and np.array_equal(outs[0], tex)
