@@ -75,8 +75,8 @@ typedef struct BrotligStreamDesc {
 } BrotligStreamDesc;
 
 /* Bytes of device workspace needed for `num_streams` streams (the reference's `meta` buffer): status words, page
- * counts, pre-conditioning tables, and 9 MiB of per-wavefront slots for the distance code of the page in flight
- * (kept out of LDS so that 16 wavefronts fit a compute unit).  One workspace per batch in flight. */
+ * counts, pre-conditioning tables, and 15 MiB of per-wavefront slots for prefix-code symbols beyond the kernel's LDS
+ * arrays (kept small so that 16 wavefronts fit a compute unit).  One workspace per batch in flight. */
 size_t BrotligDecodeWorkspaceSize(uint32_t num_streams);
 /* Workspace size that also holds the page schedule for `out_bytes` of output (one word per page): with
  * it, batches of 768 MiB and more are decoded bucket by bucket, similar pages side by side (about 12 %
