@@ -182,7 +182,8 @@ class BatchDecoder:
 
     PHASES = ("setup", "tables", "commands", "ring", "positions", "literals", "group_setup", "level_tail",
               "delta", "total", "rounds", "levels", "lv_short", "lv_bytes", "lv_long_and_far", "solo_rounds",
-              "cmd_symbol", "cmd_extra_bits", "slide", "pieces_and_far_loads", "bitmaps", "groups", "lit_steps", "lv_overlap", "team_levels")
+              "cmd_symbol", "cmd_extra_bits", "slide", "pieces_and_far_loads", "bitmaps", "groups", "lit_steps", "lv_overlap", "team_levels",
+              "level_halves", "group_halves")
 
     def phase_profile(self):
         """Per-phase shader-clock sums from the phase-timer twin of the decode kernel (diagnostics)."""

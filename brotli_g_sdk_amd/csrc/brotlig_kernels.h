@@ -87,12 +87,14 @@ struct DecodeArgs {
 // Phase timers (diagnostics build of the kernel only).
 enum : int { kPhSetup, kPhTables, kPhCommands, kPhRing, kPhPositions, kPhLiterals, kPhCopyFence, kPhCopyLevels,
              kPhDelta, kPhTotal, kPhRounds, kPhLevels, kPhLvShort, kPhLvBytes, kPhLvLong, kPhSlow,
-             kPhCmdSym, kPhCmdExtra, kPhSlide, kPhPieces, kPhBitmaps, kPhGroups, kPhLitSteps, kPhLvOverlap, kPhTeamLevels, kNumPhases };
+             kPhCmdSym, kPhCmdExtra, kPhSlide, kPhPieces, kPhBitmaps, kPhGroups, kPhLitSteps, kPhLvOverlap, kPhTeamLevels,
+             kPhLevelHalves, kPhGroupHalves, kNumPhases };   // *Halves: halves (1 or 2) that had work in an iteration
 template <bool kOn> struct PhaseClock;
 template <> struct PhaseClock<false> {
     __device__ __forceinline__ void start(unsigned long long*) {}
     __device__ __forceinline__ void lap(int) {}
     __device__ __forceinline__ void count(int, uint32_t) {}
+    __device__ __forceinline__ void halves(int, bool) {}
     __device__ __forceinline__ void flush(unsigned long long*, uint32_t) {}
 };
 // The sums live in LDS (lane 0 adds to them): fifty registers of accumulators would push the kernel's own state
@@ -114,6 +116,12 @@ template <> struct PhaseClock<true> {
         last = t;
     }
     __device__ __forceinline__ void count(int ph, uint32_t n) { if (wave::lane_id() == 0u) acc[ph] += n; }
+    // how many of the two halves take part in an iteration of a loop that runs for both (lock-step cost)
+    __device__ __forceinline__ void halves(int ph, bool mine)
+    {
+        const uint64_t m = wave::ballot64(mine);
+        count(ph, ((uint32_t)m != 0u ? 1u : 0u) + ((uint32_t)(m >> 32) != 0u ? 1u : 0u));
+    }
     __device__ __forceinline__ void flush(unsigned long long* out, uint32_t lane)
     {
         if (lane == 0u) acc[kPhTotal] = wave::clock() - t0;
@@ -151,7 +159,12 @@ constexpr uint32_t kFarSymStride = (kFarIcp + kFarDist + 63u) & ~63u;   // uint1
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
 constexpr uint32_t kShortCopy = 32;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
-constexpr uint32_t kOwnCopy = 128;          // simple copies up to this length run one-lane-per-command (batches of four 8-byte chunks)
+constexpr uint32_t kOwnCopy = 128;
+#ifndef BROTLIG_FORWARD_HOPS
+#define BROTLIG_FORWARD_HOPS 0
+#endif
+constexpr uint32_t kForwardHops = BROTLIG_FORWARD_HOPS;     // source forwarding through this many earlier copies (0 = off: it removes
+                                                            // 15 % of the dependency levels and costs as much as it saves)          // simple copies up to this length run one-lane-per-command (batches of four 8-byte chunks)
 // Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
@@ -1099,6 +1112,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             wave::sync();
             clk.lap(kPhSlide);
             clk.count(kPhGroups, 1);
+            clk.halves(kPhGroupHalves, on);
             const uint32_t span0 = gpos - view.win_base;                // window index of the group's first byte
 
             // -- 3c. my pieces in this group
@@ -1173,23 +1187,47 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             }
             wave::sync();
             clk.lap(kPhBitmaps);
-            // exact dependencies of my copy piece: the pieces (of commands before me) that own bytes of my
-            // source range inside this group; everything below the group is final
-            uint32_t dep_mask = 0;
-            if (plen && src_end > gpos && !(kAblate & kAblDeps)) {
-                const uint32_t hi_rel = src_end - 1u - gpos;
-                const uint32_t hi = L.start_cum[hi_rel >> 5] + (uint32_t)__popc(L.start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
-                uint32_t lo = 0;
-                if (psrc > gpos) {
-                    const uint32_t lo_rel = psrc - gpos;
-                    lo = L.start_cum[lo_rel >> 5] + (uint32_t)__popc(L.start_bits[lo_rel >> 5] & (0xFFFFFFFFu >> (31u - (lo_rel & 31u)))) - 1u;
+            // exact dependencies of a source range [s0, s1) of mine: the pieces (of commands before me) that own bytes
+            // of it inside this group; everything below the group is final
+            const uint32_t first_piece = ctz_u32(piece_mask);
+            auto deps_of = [&](uint32_t s0, uint32_t s1) -> uint32_t {
+                uint32_t m = 0;
+                if (s1 > gpos) {
+                    const uint32_t hi_rel = s1 - 1u - gpos;
+                    const uint32_t hi = L.start_cum[hi_rel >> 5] + (uint32_t)__popc(L.start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
+                    uint32_t lo = 0;
+                    if (s0 > gpos) {
+                        const uint32_t lo_rel = s0 - gpos;
+                        lo = L.start_cum[lo_rel >> 5] + (uint32_t)__popc(L.start_bits[lo_rel >> 5] & (0xFFFFFFFFu >> (31u - (lo_rel & 31u)))) - 1u;
+                    }
+                    // ranks lo .. hi-1 among the group's pieces; the pieces are consecutive commands (every
+                    // command has at least one byte), so rank r is lane first_piece + r.  Only pieces before
+                    // me can still be unfinished.
+                    const uint32_t lo_l = first_piece + lo, hi_l = min_u32(first_piece + hi, sl);
+                    if (hi_l > lo_l) m = ((1u << hi_l) - 1u) & ~((1u << lo_l) - 1u);
                 }
-                // ranks lo .. hi-1 among the group's pieces; the pieces are consecutive commands (every
-                // command has at least one byte), so rank r is lane first_piece + r.  Only pieces before
-                // me can still be unfinished.
-                const uint32_t first_piece = ctz_u32(piece_mask);
-                const uint32_t lo_l = first_piece + lo, hi_l = min_u32(first_piece + hi, sl);
-                if (hi_l > lo_l) dep_mask = ((1u << hi_l) - 1u) & ~((1u << lo_l) - 1u);
+                return m;
+            };
+            uint32_t dep_mask = (plen && !(kAblate & kAblDeps)) ? deps_of(psrc, src_end) : 0u;
+            // Forwarding: a piece that does not overlap itself and whose whole source lies inside ONE earlier piece of
+            // the same kind (a plain copy inside the window) reads that piece's source instead of its output -- the
+            // same bytes, one dependency level earlier (chains of copies of copies are a fifth of all levels on mixed
+            // data, two fifths on records).  Its dependencies are then those of the new range.
+            uint32_t fsrc = psrc;
+            if (kForwardHops != 0u && !(kAblate & kAblDeps)) {
+                const bool plain = plen != 0u && dist >= plen && far_len == 0u;
+                const uint32_t plain_mask = wave::half_ballot(plain);
+#pragma nounroll
+                for (uint32_t hop = 0; hop < kForwardHops; ++hop) {
+                    const bool single = plain && dep_mask != 0u && (dep_mask & (dep_mask - 1u)) == 0u && ((plain_mask & dep_mask) != 0u);
+                    if (!wave::any(single)) break;
+                    const uint32_t d = single ? ctz_u32(dep_mask) : 0u;
+                    const uint32_t d_dst = wave::half_shfl(pdst, d), d_len = wave::half_shfl(plen, d), d_src = wave::half_shfl(fsrc, d);
+                    if (single && fsrc >= d_dst && fsrc + plen <= d_dst + d_len) {
+                        fsrc = d_src + (fsrc - d_dst);
+                        dep_mask = deps_of(fsrc, fsrc + plen);
+                    }
+                }
             }
             clk.lap(kPhCopyFence);
 
@@ -1256,7 +1294,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
 
             // -- 5a. far sources: short whole pieces straight into the window, everything else into the
             //        staging area (aligned 8-byte LDS writes)
-            const uint32_t src_idx = psrc - view.win_base;              // window index of the pattern start (negative when far)
+            const uint32_t src_idx = fsrc - view.win_base;              // window index of the pattern start (negative when far)
             const uint32_t dst_idx = pdst - view.win_base;
             if (far_direct) {
                 uint8_t* d = L.win + dst_idx;
@@ -1300,6 +1338,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
                 uint32_t todo = wave::half_ballot(plen != 0u && !far_direct && !(kAblate & kAblLevels));
                 while (wave::any(todo != 0u)) {
                     clk.count(kPhLevels, 1);
+                    clk.halves(kPhLevelHalves, todo != 0u);
                     const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
                     const uint32_t ready_mask = wave::half_ballot(ready);
                     if ((kAblate & kAblTeams) || !wave::any(ready && (plen > (simple ? kOwnCopy : kShortCopy) || ((kAblate & kExpNoB) && !simple)))) {

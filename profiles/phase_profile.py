@@ -11,8 +11,11 @@ dec = api.BatchDecoder(streams)
 dec.decode()
 p = dec.phase_profile()
 tot = p["total"]
-out = {k: (v if k in ("rounds", "levels", "solo_rounds", "groups", "lit_steps", "team_levels") else round(v / tot, 4)) for k, v in p.items()}
+out = {k: (v if k in ("rounds", "levels", "solo_rounds", "groups", "lit_steps", "team_levels", "level_halves", "group_halves") else round(v / tot, 4)) for k, v in p.items()}
 out["levels_per_round"] = round(p["levels"] / max(p["rounds"], 1), 2)
+# lock-step cost: of the two halves of a wavefront, how many had work in an iteration of a loop that runs for both
+out["halves_per_level"] = round(p["level_halves"] / max(p["levels"], 1), 3)
+out["halves_per_group"] = round(p["group_halves"] / max(p["groups"], 1), 3)
 out["cycles_per_round"] = round(tot / max(p["rounds"], 1), 1)
 out["pages"] = int(sum(api.DecompressedSize(s) for s in streams) // 65536)
 out["workload"] = kind
