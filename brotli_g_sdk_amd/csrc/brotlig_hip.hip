@@ -117,6 +117,8 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
         hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, s, a);
     }
     hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, s, a);
+    if (const char* e = getenv("BROTLIG_POLICY"))       // diagnostics: pin the pairing policy (quarters of a page a free half waits)
+        HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), atoi(e), 1, s));
     if (k0) HIP_OK(hipEventRecord(k0, s));
     hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, s, a);
     if (k1) HIP_OK(hipEventRecord(k1, s));
