@@ -568,14 +568,22 @@ void parse_page_optimal(const uint8_t* data, uint32_t n, const BrotligEncodeOpti
                 if (l > best_chain) { best_chain = l; cand[nc++] = {l, p - (uint32_t)c}; if (l == maxlen) break; }
             }
         }
+        // Every copy length is priced once per start, with the first candidate that reaches it: the ring distances
+        // come first (cheapest codes), then the chain's matches from the nearest on, each strictly longer than the
+        // one before -- a farther match only contributes the lengths the nearer ones could not (the rule of brotli's
+        // shortest-path parse, which the reference's encoder drives: src/encoder/PageEncoder.cpp:87-147).
         uint32_t longest = 0;
-        for (int m = 0; m < nc; ++m) {
-            const uint32_t L = cand[m].len, dist = cand[m].dist;
-            longest = std::max(longest, L);
-            for (int si = 0; si < nstarts; ++si) {
-                const uint32_t i = starts[si];
+        for (int m = 0; m < nc; ++m) longest = std::max(longest, cand[m].len);
+        for (int si = 0; si < nstarts; ++si) {
+            const uint32_t i = starts[si];
+            uint32_t covered = 1;                                           // lengths 2 .. covered are priced
+            for (int m = 0; m < nc; ++m) {
+                const uint32_t L = cand[m].len, dist = cand[m].dist;
+                if (L <= covered) continue;
                 if (L >= 96) { relax_range(i, p, L, L, dist); continue; }  // long match: whole length only
-                relax_range(i, p, dist == node[i].ring[0] ? 2u : std::min(L, 4u), L, dist);
+                const uint32_t lmin = dist == node[i].ring[0] ? 2u : std::min(L, 4u);
+                relax_range(i, p, std::max(lmin, covered + 1u), L, dist);
+                covered = L;
             }
         }
         P.insert(p);
