@@ -13,15 +13,15 @@ extern "C" {
  *                                            uint8_t* output, BROTLIG_Feedback_Proc feedbackProc)
  *   inc/BrotligDecoder.h:33, src/BrotligDecoder.cpp:495-519 (-> :426-493).
  * Host pointers.  *output_size = capacity of `output` on entry (for a pre-conditioned stream exactly the texture
- * size, src/BrotligDecoder.cpp:478), decompressed size on return.  Pages are decoded on up to 128 threads
- * (inc/common/BrotligConstants.h:90).  `feedbackProc`: the reference's callback takes a std::string and cannot
+ * size, src/BrotligDecoder.cpp:478), decompressed size on return.  Pages are decoded by one thread per hardware
+ * thread, at most 32 (created per call; BrotligDecodeCPU takes up to the reference's 128, inc/common/BrotligConstants.h:90).  `feedbackProc`: the reference's callback takes a std::string and cannot
  * cross a C boundary; pass NULL (anything else is ignored).
  * Errors: BROTLIG_ERROR_CORRUPT_STREAM (magic), BROTLIG_ERROR_INCORRECT_STREAM_FORMAT (id != 5) as
  * src/BrotligDecoder.cpp:437-446; BROTLIG_ERROR_GENERIC for a page that fails a bounds check or an output
  * buffer of the wrong size (undefined behaviour in the reference).  Only bytes of `src` inside input_size are read. */
 BROTLIG_ERROR DecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, void* feedbackProc);
 
-/* The same with an explicit thread count (0 = one per hardware thread, at most one per page). */
+/* The same with an explicit thread count (0 = DecodeCPU's default; never more than one per page, at most 128). */
 BROTLIG_ERROR BrotligDecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, uint32_t workers);
 
 #ifdef __cplusplus
