@@ -158,19 +158,24 @@ constexpr uint32_t kFarIcp = kIcpAlphabet - kIcpSymCap, kFarDist = kDistAlphabet
 constexpr uint32_t kFarSymStride = (kFarIcp + kFarDist + 63u) & ~63u;   // uint16 per half: ICP overflow, then distance overflow
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
-constexpr uint32_t kShortCopy = 32;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
-constexpr uint32_t kOwnCopy = 128;
+#ifndef BROTLIG_TUNE_SHORT_COPY     // tunables overridable for A/B builds (profiles/tools/ab_variants.sh)
+#define BROTLIG_TUNE_SHORT_COPY 32
+#define BROTLIG_TUNE_OWN_COPY 128
+#define BROTLIG_TUNE_HIST 528
+#endif
+constexpr uint32_t kShortCopy = BROTLIG_TUNE_SHORT_COPY;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
+constexpr uint32_t kOwnCopy = BROTLIG_TUNE_OWN_COPY;             // simple copies up to this length run one-lane-per-command (batches of four 8-byte chunks)
 #ifndef BROTLIG_FORWARD_HOPS
 #define BROTLIG_FORWARD_HOPS 0
 #endif
 constexpr uint32_t kForwardHops = BROTLIG_FORWARD_HOPS;     // source forwarding through this many earlier copies (0 = off: it removes
-                                                            // 15 % of the dependency levels and costs as much as it saves)          // simple copies up to this length run one-lane-per-command (batches of four 8-byte chunks)
+                                                            // 15 % of the dependency levels and costs as much as it saves)
 // Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
 // flushed to global memory in aligned 16-byte stores when it slides.
 constexpr uint32_t kWin = 1488;
-constexpr uint32_t kHist = 528;             // history kept across a slide (>= kRoundMax + 16: see the slide below)
+constexpr uint32_t kHist = BROTLIG_TUNE_HIST;             // history kept across a slide (>= kRoundMax + 16: see the slide below)
 constexpr uint32_t kRoundMax = 512;          // bytes assembled per group
 static_assert(kHist >= kRoundMax + 16u && kWin >= kHist + 16u + kRoundMax, "window: history + one group");
 constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
