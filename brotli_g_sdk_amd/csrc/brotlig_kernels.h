@@ -141,8 +141,19 @@ enum : uint32_t { kAblLevels = 1u, kAblTeams = 2u, kAblOverlap = 4u, kAblFar = 8
 constexpr uint32_t kAblate = BROTLIG_ABLATE;
 
 // ---- tunables ---------------------------------------------------------------------------
+// (overridable for A/B builds of the kernel: profiles/tools/ab_variants.sh)
+#ifndef BROTLIG_TUNE_SHORT_COPY
+#define BROTLIG_TUNE_SHORT_COPY 32
+#define BROTLIG_TUNE_OWN_COPY 128
+#define BROTLIG_TUNE_HIST 528
+#endif
+#ifndef BROTLIG_TUNE_ROUND_MAX
+#define BROTLIG_TUNE_ROUND_MAX 512
+#define BROTLIG_TUNE_WIN 1488
+#define BROTLIG_TUNE_DIST_LUT_BITS 8
+#endif
 constexpr int kLutBitsIcp = 8;
-constexpr int kLutBitsDist = 8;
+constexpr int kLutBitsDist = BROTLIG_TUNE_DIST_LUT_BITS;
 constexpr int kLutBitsLit = 8;
 // Symbols in canonical-code order ("sorted" arrays, read for codes longer than the LUT index): LDS holds the first
 // kIcpSymCap / kDistSymCap of them, global memory (DecodeArgs::far_syms) the rest.  Pages of the benchmark's data
@@ -158,11 +169,6 @@ constexpr uint32_t kFarIcp = kIcpAlphabet - kIcpSymCap, kFarDist = kDistAlphabet
 constexpr uint32_t kFarSymStride = (kFarIcp + kFarDist + 63u) & ~63u;   // uint16 per half: ICP overflow, then distance overflow
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
-#ifndef BROTLIG_TUNE_SHORT_COPY     // tunables overridable for A/B builds (profiles/tools/ab_variants.sh)
-#define BROTLIG_TUNE_SHORT_COPY 32
-#define BROTLIG_TUNE_OWN_COPY 128
-#define BROTLIG_TUNE_HIST 528
-#endif
 constexpr uint32_t kShortCopy = BROTLIG_TUNE_SHORT_COPY;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
 constexpr uint32_t kOwnCopy = BROTLIG_TUNE_OWN_COPY;             // simple copies up to this length run one-lane-per-command (batches of four 8-byte chunks)
 #ifndef BROTLIG_FORWARD_HOPS
@@ -174,9 +180,9 @@ constexpr uint32_t kForwardHops = BROTLIG_FORWARD_HOPS;     // source forwarding
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
 // flushed to global memory in aligned 16-byte stores when it slides.
-constexpr uint32_t kWin = 1488;
+constexpr uint32_t kWin = BROTLIG_TUNE_WIN;
 constexpr uint32_t kHist = BROTLIG_TUNE_HIST;             // history kept across a slide (>= kRoundMax + 16: see the slide below)
-constexpr uint32_t kRoundMax = 512;          // bytes assembled per group
+constexpr uint32_t kRoundMax = BROTLIG_TUNE_ROUND_MAX;     // bytes assembled per group (a multiple of 32; the flush and the slide move up to 1024 bytes)
 static_assert(kHist >= kRoundMax + 16u && kWin >= kHist + 16u + kRoundMax, "window: history + one group");
 constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
 static_assert(kStageBytes >= kRoundMax + 64u, "the staging area also holds a group's literals, with slack for 8-byte reads");
@@ -230,7 +236,8 @@ static_assert(sizeof(uint16_t) * ((1 << kLutBitsDist) + (1 << kLutBitsLit)) + kS
 static_assert(sizeof(uint16_t) * (1 << kLutBitsLit) + kStageBytes >= kTableScratchBytes, "literal build scratch");
 static_assert(__builtin_offsetof(PageLds, lut_dist) == sizeof(uint16_t) * (1 << kLutBitsIcp), "LUTs must be contiguous");
 static_assert(__builtin_offsetof(PageLds, stage) == sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)), "staging area must follow the LUTs");
-static_assert(kHist + 16u <= 1024u && kWin - kHist >= 512u + 16u, "the slide moves at most two 16-byte pieces per lane; a group fits behind the history");
+static_assert(kHist + 16u <= 1024u && kRoundMax + 16u <= 1024u && kRoundMax % 32u == 0u && kWin - kHist >= kRoundMax + 16u,
+              "the slide and the flush move at most two 16-byte pieces per lane; a group fits behind the history");
 static_assert(kWin + 16 >= kIcpAlphabet, "the window holds the code lengths during the table build");
 
 struct __attribute__((aligned(16))) WaveLds {
