@@ -131,7 +131,6 @@ struct PageCtx {
     SubReader sub[kNumStreams];
     Code icp, dist, lit;
     std::vector<uint8_t> queue;             // literal queue (PageDecoder.cpp:164-166)
-    std::vector<uint8_t> temp;              // conditioned-space page for pre-conditioned streams
 };
 
 // SURVEY.md A.5 / src/decoder/BrotligHuffmanTable.cpp:73-205: the description is read round-robin over the 32
@@ -143,7 +142,7 @@ bool read_code(PageCtx& P, Code& c, uint32_t alphabet)
     const uint32_t type = hdr & 3u;
     if (type == 0u) {                                                           // trivial: one symbol
         c.single = true; c.single_sym = P.sub[0].read(maxbits); c.maxlen = 0;
-        return c.single_sym < alphabet || alphabet == kIcpAlphabet;             // (an ICP value above 727 cannot occur: 10 bits, 728..1023 rejected below)
+        return c.single_sym < alphabet;
     }
     uint8_t len[kIcpAlphabet];
     memset(len, 0, sizeof len);
