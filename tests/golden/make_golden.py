@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 from brotli_g_sdk_amd import datagen as D, encoder as E  # noqa: E402
-from cases import skewed  # noqa: E402
+from cases import many_command_shapes, many_distances, skewed  # noqa: E402
 from helpers import oracle_decode  # noqa: E402
 
 N = 65536 + 9000
@@ -35,6 +35,9 @@ CASES = {
     "mixed_128k": (D.mixed(2 * 65536, 10), dict(page_size=131072)),
     "bc1_swz_delta": (D.bc_texture(1, 64, 64, seed=11), dict(precondition=dict(format=1, width_blocks=64, height_blocks=64, swizzle=1, delta=1))),
     "bc3_mips": (D.bc_texture(3, 40, 24, seed=12, num_mips=3), dict(precondition=dict(format=3, width_blocks=40, height_blocks=24, num_mips=3, swizzle=1, delta=1))),
+    # more ICP / distance symbols in a page than the decoder's LDS arrays hold (kIcpSymCap, kDistSymCap)
+    "many_command_shapes_128k": (many_command_shapes(131072 + 500, 5), dict(page_size=131072)),
+    "many_distances_np3": (many_distances(65536 + 500, 6), dict(npostfix=3, ndirect_m=15)),
     "bc5_pitch": (D.bc_texture(5, 33, 17, seed=13, pitch_bytes=33 * 16 + 7), dict(precondition=dict(format=5, width_blocks=33, height_blocks=17, swizzle=1, delta=1, pitch_bytes=33 * 16 + 7))),
 }
 
