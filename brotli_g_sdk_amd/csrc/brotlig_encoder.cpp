@@ -325,6 +325,11 @@ struct Parser {
     uint32_t match_len(uint32_t a, uint32_t b, uint32_t maxlen) const
     {
         uint32_t l = 0;
+        while (l + 8u <= maxlen) {                                  // eight bytes a step (little-endian: the first mismatch is the lowest set bit)
+            uint64_t x, y; memcpy(&x, d + a + l, 8); memcpy(&y, d + b + l, 8);
+            if (x != y) return l + ((uint32_t)__builtin_ctzll(x ^ y) >> 3);
+            l += 8u;
+        }
         while (l < maxlen && d[a + l] == d[b + l]) ++l;
         return l;
     }
