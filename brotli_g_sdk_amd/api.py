@@ -28,14 +28,56 @@ class _StreamDesc(ctypes.Structure):
                 ("in_size", ctypes.c_uint64), ("out_capacity", ctypes.c_uint64)]
 
 
+class DeviceBatch(ctypes.Structure):
+    """BrotligDeviceBatch (include/brotlig_amd.h): one shard of a multi-device decode."""
+    _fields_ = [("device", ctypes.c_int32), ("num_streams", ctypes.c_uint32),
+                ("d_in", ctypes.c_void_p), ("in_bytes", ctypes.c_uint64),
+                ("d_out", ctypes.c_void_p), ("out_bytes", ctypes.c_uint64),
+                ("d_streams", ctypes.c_void_p),
+                ("d_workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_uint64),
+                ("d_scratch", ctypes.c_void_p), ("hip_stream", ctypes.c_void_p),
+                ("result", ctypes.c_int32), ("reserved", ctypes.c_uint32),
+                ("kernel_ms", ctypes.c_double), ("wall_ms", ctypes.c_double)]
+
+
+ABI_VERSION = 3         # BROTLIG_AMD_ABI_VERSION: the batch entry points carry it in their symbol names
+_VERSIONED = ("BrotligDecodeWorkspaceSize", "BrotligDecodeWorkspaceSizeFor", "BrotligDecodeBatchDevice", "BrotligDecodeBatchStatus",
+              "BrotligDecodeBatchTimed", "BrotligDecodePhaseProfile", "BrotligDecodeBatchMultiDevice")
+
 _lib = None
+
+
+class _Lib:
+    """The shared library with the header's symbol-version macros applied: L.BrotligDecodeBatchDevice is the symbol
+    BrotligDecodeBatchDevice_v3, as it is for a C caller that includes brotlig_amd.h."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+
+    def __getattr__(self, name):
+        return getattr(self._cdll, f"{name}_v{ABI_VERSION}" if name in _VERSIONED else name)
 
 
 def lib():
     """Loads libbrotlig_hip.so (building it in-tree with hipcc if needed).  Raises if absent."""
     global _lib
     if _lib is None:
-        L = ctypes.CDLL(_build.build_hip())
+        L = _Lib(ctypes.CDLL(_build.build_hip()))
+        L.BrotligAbiVersion.restype = ctypes.c_uint32
+        if L.BrotligAbiVersion() != ABI_VERSION:
+            raise RuntimeError("libbrotlig_hip.so has ABI version %d, this mirror expects %d" % (L.BrotligAbiVersion(), ABI_VERSION))
+        L.BrotligShardPlan.restype = ctypes.c_int
+        L.BrotligShardPlan.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        L.BrotligDecodeBatchMultiDevice.restype = ctypes.c_int
+        L.BrotligDecodeBatchMultiDevice.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.BrotligContextCreate.restype = ctypes.c_int
+        L.BrotligContextCreate.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.BrotligContextDestroy.restype = None
+        L.BrotligContextDestroy.argtypes = [ctypes.c_void_p]
+        L.BrotligContextDecodeGPU.restype = ctypes.c_int
+        L.BrotligContextDecodeGPU.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32),
+                                              ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         L.DecompressedSize.restype = ctypes.c_uint32
         L.DecompressedSize.argtypes = [ctypes.c_void_p]
         L.DecodeGPU.restype = ctypes.c_int
@@ -94,6 +136,73 @@ def DecodeGPU(src, output_size=None):
     if rc != BROTLIG_OK:
         raise BrotligError(rc, "DecodeGPU")
     return out[:osz.value], t.value
+
+
+class Context:
+    """BrotligContext: DecodeGPU with device buffers, stream and events kept between calls."""
+
+    def __init__(self, device=-1):
+        self._h = ctypes.c_void_p()
+        rc = lib().BrotligContextCreate(int(device), ctypes.byref(self._h))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligContextCreate")
+
+    def close(self):
+        if self._h:
+            lib().BrotligContextDestroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def DecodeGPU(self, src, output_size=None):
+        a = np.ascontiguousarray(np.frombuffer(src, dtype=np.uint8) if not isinstance(src, np.ndarray) else src, dtype=np.uint8)
+        cap = DecompressedSize(a) if output_size is None else int(output_size)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        osz = ctypes.c_uint32(cap)
+        t = ctypes.c_double(0.0)
+        rc = lib().BrotligContextDecodeGPU(self._h, len(a), a.ctypes.data, ctypes.byref(osz), out.ctypes.data, ctypes.byref(t))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligContextDecodeGPU")
+        return out[:osz.value], t.value
+
+
+def ShardPlan(in_sizes, num_shards):
+    """BrotligShardPlan: contiguous runs of streams, one per shard, balanced by compressed bytes.  Returns the
+    num_shards + 1 run boundaries.  Host arithmetic only (no device needed)."""
+    sizes = np.ascontiguousarray(in_sizes, dtype=np.uint64)
+    first = np.zeros(int(num_shards) + 1, dtype=np.uint32)
+    rc = lib().BrotligShardPlan(sizes.ctypes.data, len(sizes), int(num_shards), first.ctypes.data)
+    if rc != BROTLIG_OK:
+        raise BrotligError(rc, "BrotligShardPlan")
+    return [int(x) for x in first]
+
+
+def DecodeBatchMultiDevice(decoders, warmup=0, steps=1, streams=None):
+    """BrotligDecodeBatchMultiDevice over `decoders` (BatchDecoder objects, one per shard, each on its own device -- or
+    several on one).  Returns (max kernel ms, max wall ms, per-shard list of (result, kernel_ms, wall_ms))."""
+    n = len(decoders)
+    arr = (DeviceBatch * n)()
+    for i, d in enumerate(decoders):
+        b = arr[i]
+        b.device = d.device.index or 0
+        b.num_streams = d.n
+        b.d_in, b.in_bytes = d.d_in.data_ptr(), d.in_bytes
+        b.d_out, b.out_bytes = d.d_out.data_ptr(), d.out_bytes
+        b.d_streams = d.d_desc.data_ptr()
+        b.d_workspace, b.workspace_bytes = d.d_ws.data_ptr(), d.ws_bytes
+        b.d_scratch = d.d_scratch.data_ptr() if d.d_scratch is not None else None
+        b.hip_stream = streams[i] if streams is not None else None
+    mk, mw = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    rc = lib().BrotligDecodeBatchMultiDevice(ctypes.addressof(arr), n, ctypes.sizeof(DeviceBatch), int(warmup), int(steps),
+                                             ctypes.byref(mk), ctypes.byref(mw))
+    per = [(arr[i].result, arr[i].kernel_ms, arr[i].wall_ms) for i in range(n)]
+    if rc != BROTLIG_OK:
+        raise BrotligError(rc, "BrotligDecodeBatchMultiDevice")
+    return mk.value, mw.value, per
 
 
 def DeviceSelfTest():

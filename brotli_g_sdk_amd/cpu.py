@@ -20,17 +20,32 @@ def lib():
         L.DecodeCPU.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p, ctypes.c_void_p]
         L.BrotligDecodeCPU.restype = ctypes.c_int
         L.BrotligDecodeCPU.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p, ctypes.c_uint32]
+        L.BrotligDecodeCPUWithFeedback.restype = ctypes.c_int
+        L.BrotligDecodeCPUWithFeedback.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p,
+                                                   ctypes.c_uint32, FEEDBACK_PROC, ctypes.c_void_p]
         _lib = L
     return _lib
 
 
-def DecodeCPU(src, output_size=None, workers=None):
-    """BROTLIG_ERROR DecodeCPU(input_size, src, output_size, output, feedbackProc).  Returns (code, output ndarray)."""
+# int (*BrotligFeedbackProc)(int type, const char* message, void* user) -- include/brotlig_amd_cpu.h
+FEEDBACK_PROC = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p)
+BROTLIG_PROGRESS, BROTLIG_WARNING = 0, 1
+BROTLIG_ABORTED = 1
+
+
+def DecodeCPU(src, output_size=None, workers=None, feedbackProc=None):
+    """BROTLIG_ERROR DecodeCPU(input_size, src, output_size, output, feedbackProc).  Returns (code, output ndarray).
+    `feedbackProc(type, message) -> bool` is the reference's callback (inc/common/BrotligCommon.h:92): called once per
+    page from the decoding threads, True aborts (code BROTLIG_ABORTED).  It travels through the C twin
+    BrotligDecodeCPUWithFeedback; the reference-named entry itself only accepts NULL."""
     a = np.ascontiguousarray(np.frombuffer(src, dtype=np.uint8) if not isinstance(src, np.ndarray) else src, dtype=np.uint8)
     cap = int(lib().DecompressedSize(a.ctypes.data)) if output_size is None and len(a) >= 8 else int(output_size or 0)
     out = np.empty(max(cap, 1), dtype=np.uint8)
     osz = ctypes.c_uint32(cap)
-    if workers is None:
+    if feedbackProc is not None:
+        cb = FEEDBACK_PROC(lambda t, m, u: 1 if feedbackProc(t, m.decode()) else 0)
+        rc = lib().BrotligDecodeCPUWithFeedback(len(a), a.ctypes.data, ctypes.byref(osz), out.ctypes.data, int(workers or 0), cb, None)
+    elif workers is None:
         rc = lib().DecodeCPU(len(a), a.ctypes.data, ctypes.byref(osz), out.ctypes.data, None)
     else:
         rc = lib().BrotligDecodeCPU(len(a), a.ctypes.data, ctypes.byref(osz), out.ctypes.data, int(workers))

@@ -11,7 +11,10 @@
 // de-conditioning as a block gather after the pages instead of a per-byte scatter.
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstring>
+#include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -148,6 +151,9 @@ bool read_code(PageCtx& P, Code& c, uint32_t alphabet)
     memset(len, 0, sizeof len);
     if (type == 1u) {                                                           // simple: 2..4 symbols, fixed shapes (:26-38,:98-120)
         const uint32_t nsym = ((hdr >> 2) & 3u) + 1u, tree_select = (hdr >> 4) & 1u;
+        // one symbol is not a simple code: the reference indexes FixedCodelengths[nsym - 2] (out of bounds,
+        // BrotligHuffmanTable.cpp:103) and no encoder writes it -- rejected here and in the GPU kernel alike
+        if (nsym < 2u) return false;
         // code lengths per shape: {1,1} {1,2,2} {2,2,2,2} {1,2,3,3}
         const uint32_t shape = nsym < 4u ? nsym - 2u : (tree_select ? 3u : 2u);
         uint32_t syms[4];
@@ -157,8 +163,7 @@ bool read_code(PageCtx& P, Code& c, uint32_t alphabet)
         for (uint32_t e = 0; e < (1u << kRootBits); ++e) {
             const uint32_t b0 = e & 1u, b1 = (e >> 1) & 1u, b2 = (e >> 2) & 1u;
             uint32_t k, l;
-            if (nsym == 1u) { k = 0; l = 1; }
-            else if (shape == 0u) { k = b0; l = 1; }
+            if (shape == 0u) { k = b0; l = 1; }
             else if (shape == 1u) { k = b0 ? 1u + b1 : 0u; l = b0 ? 2u : 1u; }
             else if (shape == 2u) { k = b0 * 2u + b1; l = 2; }
             else { k = !b0 ? 0u : (!b1 ? 1u : 2u + b2); l = !b0 ? 1u : (!b1 ? 2u : 3u); }
@@ -254,6 +259,8 @@ struct Job {
     const uint8_t* table; const uint8_t* pages; uint64_t pages_size;
     uint8_t* out; StreamInfo si; const Dc* dc;
     std::atomic<uint32_t> next{0}; std::atomic<int> error{0};
+    BrotligFeedbackProc feedback = nullptr; void* user = nullptr;           // per-page progress callback (may be null)
+    std::atomic<int> aborted{0};
 };
 
 inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
@@ -378,7 +385,7 @@ void worker(Job* J, uint8_t* cond)
     const StreamInfo& si = J->si;
     for (;;) {
         const uint32_t i = J->next.fetch_add(1);
-        if (i >= si.num_pages || J->error.load()) return;
+        if (i >= si.num_pages || J->error.load() || J->aborted.load()) return;
         const uint64_t off = i ? rd32(J->table + 4u * i) : 0u;                  // src/BrotligDecoder.cpp:310
         const uint64_t size = i + 1u < si.num_pages ? (uint64_t)rd32(J->table + 4u * (i + 1u)) - off : rd32(J->table);
         const uint32_t out_size = (i + 1u == si.num_pages && si.last_page_size) ? si.last_page_size : si.page_size;
@@ -386,6 +393,11 @@ void worker(Job* J, uint8_t* cond)
         if (off > J->pages_size || size > 0xFFFFFFFFull ||
             !decode_page(P, J->pages + off, (uint32_t)size, J->pages_size - off, dst, out_size, si.page_size, i * si.page_size, J->dc))
             J->error.store(1);
+        if (J->feedback) {                                                      // src/BrotligDecoder.cpp:318-325
+            char msg[48];
+            snprintf(msg, sizeof msg, "%f", 100.f * ((float)i / (float)si.num_pages));     // std::to_string(float)
+            if (J->feedback(BROTLIG_PROGRESS, msg, J->user)) { J->aborted.store(1); return; }
+        }
     }
 }
 
@@ -414,7 +426,10 @@ void decondition(const Dc& dc, const uint8_t* cond, uint8_t* tex)
 
 }  // namespace
 
-extern "C" BROTLIG_ERROR BrotligDecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, uint32_t workers)
+namespace {
+
+BROTLIG_ERROR decode_stream(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, uint32_t workers,
+                            BrotligFeedbackProc feedback, void* user)
 {
     if (!src || !output || !output_size || input_size < 8u) return BROTLIG_ERROR_CORRUPT_STREAM;
     const uint32_t w0 = rd32(src), w1 = rd32(src + 4);
@@ -429,13 +444,13 @@ extern "C" BROTLIG_ERROR BrotligDecodeCPU(uint32_t input_size, const uint8_t* sr
     std::vector<uint8_t> cond;
     if (si.preconditioned) {                                                    // :466-481: the texture is *output_size bytes
         if (!dc.init(rd32(src + 8), rd32(src + 12), *output_size) || usize != *output_size) return BROTLIG_ERROR_GENERIC;
-        memset(output, 0, *output_size);                                        // row-pitch padding stays zero (:448)
         cond.resize((size_t)si.num_pages * si.page_size);
     }
+    memset(output, 0, *output_size);                                            // :448 -- every stream, like the reference
     Job J;
     J.src = src; J.src_size = input_size; J.table = src + si.header_bytes; J.pages = J.table + 4ull * si.num_pages;
     J.pages_size = input_size - si.header_bytes - 4ull * si.num_pages;
-    J.out = output; J.si = si; J.dc = &dc;
+    J.out = output; J.si = si; J.dc = &dc; J.feedback = feedback; J.user = user;
     // default: one worker per hardware thread up to 32 -- threads are created per call, and on the 256-thread host of
     // the MI355X box 32 workers decode 15 GB/s where 64 and more fall back to 10 (profiles/r02_cpu_decode.json)
     uint32_t nw = workers ? workers : std::min(std::thread::hardware_concurrency(), 32u);
@@ -443,13 +458,45 @@ extern "C" BROTLIG_ERROR BrotligDecodeCPU(uint32_t input_size, const uint8_t* sr
     if (nw > si.num_pages) nw = si.num_pages ? si.num_pages : 1u;
     if (nw > 128u) nw = 128u;                                                   // inc/common/BrotligConstants.h:90
     std::vector<std::thread> pool;
-    for (uint32_t t = 1; t < nw; ++t) pool.emplace_back(worker, &J, cond.data());
-    worker(&J, cond.data());
+    pool.reserve(nw);
+    // a thread that cannot be created (EAGAIN) is not an error: the workers that did start, and this thread, take
+    // the pages from the shared counter
+    for (uint32_t t = 1; t < nw; ++t) {
+        try { pool.emplace_back(worker, &J, cond.data()); }
+        catch (const std::system_error&) { break; }
+    }
+    bool threw = false;
+    try { worker(&J, cond.data()); }
+    catch (...) { J.error.store(1); threw = true; }                             // (bad_alloc of the page context)
     for (auto& t : pool) t.join();
-    if (J.error.load()) return BROTLIG_ERROR_GENERIC;
+    if (threw || J.error.load()) return BROTLIG_ERROR_GENERIC;
+    if (J.aborted.load()) return BROTLIG_ABORTED;
     if (si.preconditioned) decondition(dc, cond.data(), output);
     *output_size = (uint32_t)usize;                                             // :490
     return BROTLIG_OK;
+}
+
+// nothing C++ may leave an extern "C" entry: allocation failures become BROTLIG_ERROR_GENERIC
+template <class F> BROTLIG_ERROR guarded(F&& f)
+{
+    try { return f(); }
+    catch (...) { return BROTLIG_ERROR_GENERIC; }
+}
+
+}  // namespace
+
+extern "C" BROTLIG_ERROR BrotligDecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, uint32_t workers)
+{
+    return guarded([&] { return decode_stream(input_size, src, output_size, output, workers, nullptr, nullptr); });
+}
+
+// C-safe twin of the reference's feedback path (src/BrotligDecoder.cpp:318-325): `feedback` is called once per decoded
+// page, from the worker thread that decoded it, with BROTLIG_PROGRESS and the percentage as text; a non-zero return
+// stops the decode (BROTLIG_ABORTED, the output is then incomplete).
+extern "C" BROTLIG_ERROR BrotligDecodeCPUWithFeedback(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output,
+                                                      uint32_t workers, BrotligFeedbackProc feedback, void* user)
+{
+    return guarded([&] { return decode_stream(input_size, src, output_size, output, workers, feedback, user); });
 }
 
 // inc/BrotligDecoder.h:32, src/BrotligDecoder.cpp:35-39: no validation.  (libbrotlig_hip.so exports the same
@@ -461,9 +508,11 @@ extern "C" uint32_t DecompressedSize(uint8_t* src)
     return uncompressed_size(si);
 }
 
-// The reference's prototype (inc/BrotligDecoder.h:33).  Its callback takes a std::string and cannot cross a C
-// boundary; pass NULL (a non-NULL callback is ignored).
-extern "C" BROTLIG_ERROR DecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, void* /*feedbackProc*/)
+// The reference's prototype (inc/BrotligDecoder.h:33).  Its callback type takes a std::string by value and cannot
+// cross a C boundary, so this entry only accepts NULL there; callers that want progress / abort use
+// BrotligDecodeCPUWithFeedback.  A non-NULL pointer is rejected rather than called with the wrong convention.
+extern "C" BROTLIG_ERROR DecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, void* feedbackProc)
 {
-    return BrotligDecodeCPU(input_size, src, output_size, output, 0u);
+    if (feedbackProc != nullptr) return BROTLIG_ERROR_GENERIC;
+    return guarded([&] { return decode_stream(input_size, src, output_size, output, 0u, nullptr, nullptr); });
 }

@@ -8,8 +8,13 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <new>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "brotlig_amd.h"
@@ -204,8 +209,31 @@ extern "C" BROTLIG_ERROR BrotligDecodeBatchTimed(const void* d_in, uint64_t in_b
     return BROTLIG_OK;
 }
 
-extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, const uint8_t* input,
-                                   uint32_t* output_size, uint8_t* output, double* time_ms)
+// ---- reusable decode context ("a reusable context object is allowed ... but must be optional") --------
+// Device buffers that only grow, one stream, two events: DecodeGPU through a context costs two copies and the
+// launches, not five hipMalloc / hipFree pairs (sample/BrotligGPUDecoder.cpp:260-748 rebuilds its whole D3D12 state per call).
+struct BrotligContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Event e0, e1;
+    DevBuf in, out, scratch, ws, desc;
+    size_t in_cap = 0, out_cap = 0, scratch_cap = 0, ws_cap = 0;
+};
+
+namespace {
+
+BROTLIG_ERROR grow(DevBuf& b, size_t& cap, size_t need)
+{
+    if (need <= cap) return BROTLIG_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; cap = 0; }
+    const size_t want = need + need / 4u;                               // headroom: assets of similar size reuse it
+    HIP_OK(hipMalloc(&b.p, want));
+    cap = want;
+    return BROTLIG_OK;
+}
+
+// DecodeGPU proper; `c` owns every device resource it needs
+BROTLIG_ERROR decode_gpu(BrotligContext& c, uint32_t input_size, const uint8_t* input, uint32_t* output_size, uint8_t* output, double* time_ms)
 {
     if (!input || !output || !output_size || input_size < 8) return BROTLIG_ERROR_CORRUPT_STREAM;
     uint32_t w0, w1;
@@ -220,31 +248,201 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
 
     const uint64_t in_alloc = ((uint64_t)input_size + 15u) & ~15ull;
     const uint64_t out_alloc = (((uint64_t)si.num_pages * si.page_size) + 15u) & ~15ull;
-    DevBuf d_in, d_out, d_scratch, d_ws, d_desc;
-    HIP_OK(hipMalloc(&d_in.p, in_alloc + 64));
-    HIP_OK(hipMalloc(&d_out.p, out_alloc + 64));                        // copies read up to 7 bytes past a page
-    if (si.preconditioned) HIP_OK(hipMalloc(&d_scratch.p, out_alloc + 64));
     const size_t ws_size = BrotligDecodeWorkspaceSizeFor(1, out_alloc);
-    HIP_OK(hipMalloc(&d_ws.p, ws_size));
-    HIP_OK(hipMalloc(&d_desc.p, sizeof(BrotligStreamDesc)));
+    if (BROTLIG_ERROR e = grow(c.in, c.in_cap, in_alloc + 64)) return e;
+    if (BROTLIG_ERROR e = grow(c.out, c.out_cap, out_alloc + 64)) return e;         // copies read up to 7 bytes past a page
+    if (si.preconditioned) if (BROTLIG_ERROR e = grow(c.scratch, c.scratch_cap, out_alloc + 64)) return e;
+    if (BROTLIG_ERROR e = grow(c.ws, c.ws_cap, ws_size)) return e;
+    if (!c.desc.p) HIP_OK(hipMalloc(&c.desc.p, sizeof(BrotligStreamDesc)));
     const BrotligStreamDesc desc{0, 0, input_size, *output_size};
-    HIP_OK(hipMemset(static_cast<uint8_t*>(d_in.p) + (in_alloc + 64 - 80), 0, 80));
-    HIP_OK(hipMemcpy(d_in.p, input, input_size, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_desc.p, &desc, sizeof desc, hipMemcpyHostToDevice));
-
-    Event e0, e1;
-    HIP_OK(e0.create()); HIP_OK(e1.create());
-    const DecodeArgs a = make_args(d_in.p, input_size, d_out.p, out_alloc, static_cast<BrotligStreamDesc*>(d_desc.p), 1,
-                                   d_ws.p, ws_size, d_scratch.p);
-    BROTLIG_ERROR err = enqueue(a, nullptr, e0.e, e1.e);
-    if (err == BROTLIG_OK) err = BrotligDecodeBatchStatus(d_ws.p, nullptr);
+    HIP_OK(hipMemsetAsync(static_cast<uint8_t*>(c.in.p) + (in_alloc + 64 - 80), 0, 80, c.stream));
+    HIP_OK(hipMemcpyAsync(c.in.p, input, input_size, hipMemcpyHostToDevice, c.stream));
+    HIP_OK(hipMemcpyAsync(c.desc.p, &desc, sizeof desc, hipMemcpyHostToDevice, c.stream));
+    HIP_OK(hipStreamSynchronize(c.stream));                             // `desc` lives on this frame
+    const DecodeArgs a = make_args(c.in.p, input_size, c.out.p, out_alloc, static_cast<BrotligStreamDesc*>(c.desc.p), 1,
+                                   c.ws.p, ws_size, si.preconditioned ? c.scratch.p : nullptr);
+    BROTLIG_ERROR err = enqueue(a, c.stream, c.e0.e, c.e1.e);
+    if (err == BROTLIG_OK) err = BrotligDecodeBatchStatus(c.ws.p, c.stream);
     float ms = 0.f;
-    if (err == BROTLIG_OK && hipEventElapsedTime(&ms, e0.e, e1.e) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
+    if (err == BROTLIG_OK && hipEventElapsedTime(&ms, c.e0.e, c.e1.e) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
     if (err != BROTLIG_OK) return err;
-    HIP_OK(hipMemcpy(output, d_out.p, out_size, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpyAsync(output, c.out.p, out_size, hipMemcpyDeviceToHost, c.stream));
+    HIP_OK(hipStreamSynchronize(c.stream));
     *output_size = out_size;                                            // src/BrotligDecoder.cpp:490
     if (time_ms) *time_ms = ms;
     return BROTLIG_OK;
+}
+
+BROTLIG_ERROR context_init(BrotligContext& c, int device)
+{
+    if (device < 0) HIP_OK(hipGetDevice(&device)); else HIP_OK(hipSetDevice(device));
+    c.device = device;
+    HIP_OK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_OK(c.e0.create()); HIP_OK(c.e1.create());
+    return BROTLIG_OK;
+}
+
+}  // namespace
+
+extern "C" BROTLIG_ERROR BrotligContextCreate(int device, BrotligContext** out)
+{
+    if (!out) return BROTLIG_ERROR_GENERIC;
+    *out = nullptr;
+    BrotligContext* c = new (std::nothrow) BrotligContext;
+    if (!c) return BROTLIG_ERROR_GENERIC;
+    if (BROTLIG_ERROR e = context_init(*c, device)) { BrotligContextDestroy(c); return e; }
+    *out = c;
+    return BROTLIG_OK;
+}
+
+extern "C" void BrotligContextDestroy(BrotligContext* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    delete c;
+}
+
+extern "C" BROTLIG_ERROR BrotligContextDecodeGPU(BrotligContext* c, uint32_t input_size, const uint8_t* input,
+                                                 uint32_t* output_size, uint8_t* output, double* time_ms)
+{
+    if (!c) return BROTLIG_ERROR_GENERIC;
+    HIP_OK(hipSetDevice(c->device));
+    return decode_gpu(*c, input_size, input, output_size, output, time_ms);
+}
+
+// The reference's entry (sample/BrotligGPUDecoder.h:24): stateless -- a context for the length of the call.
+extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, const uint8_t* input,
+                                   uint32_t* output_size, uint8_t* output, double* time_ms)
+{
+    BrotligContext c;
+    if (BROTLIG_ERROR e = context_init(c, -1)) return e;
+    const BROTLIG_ERROR err = decode_gpu(c, input_size, input, output_size, output, time_ms);
+    if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
+    return err;
+}
+
+// ---- multi-device fan-out (SURVEY.md 8(b) row 4 "plus a multi-GPU wrapper", 8(e)) ------------------------------------
+// Streams are independent, so a batch shards with no exchange between devices: contiguous runs of streams, one run per
+// device, cut so that the largest run's COMPRESSED bytes are as small as possible (the cost of a page follows its
+// compressed size, not its 64 KiB of output; 8(e) last row).  Streams are never split (a pre-conditioned stream's pages
+// scatter over its whole texture).  The reference's analogue is the fan-out of pages over host threads,
+// src/BrotligDecoder.cpp:356-375, and of streams over the shader's queue, BrotliGCompute.hlsl:1757-1881.
+extern "C" BROTLIG_ERROR BrotligShardPlan(const uint64_t* in_sizes, uint32_t num_streams, uint32_t num_shards, uint32_t* first)
+{
+    if (!in_sizes || !first || num_shards == 0u) return BROTLIG_ERROR_GENERIC;
+    // smallest cap such that a left-to-right packing needs at most num_shards runs
+    uint64_t lo = 0, hi = 0;
+    for (uint32_t i = 0; i < num_streams; ++i) { lo = in_sizes[i] > lo ? in_sizes[i] : lo; hi += in_sizes[i]; }
+    auto runs_needed = [&](uint64_t cap) {
+        uint32_t runs = 1; uint64_t acc = 0;
+        for (uint32_t i = 0; i < num_streams; ++i) {
+            if (acc + in_sizes[i] > cap && acc != 0u) { ++runs; acc = 0; }
+            acc += in_sizes[i];
+        }
+        return runs;
+    };
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2u; if (runs_needed(mid) <= num_shards) hi = mid; else lo = mid + 1u; }
+    // pack under that cap, but never leave a later shard without a stream while streams remain
+    uint32_t i = 0;
+    for (uint32_t g = 0; g < num_shards; ++g) {
+        first[g] = i;
+        uint64_t acc = 0;
+        const uint32_t shards_after = num_shards - 1u - g;
+        while (i < num_streams && (acc == 0u || acc + in_sizes[i] <= lo) && num_streams - i > shards_after) acc += in_sizes[i++];
+        if (shards_after == 0u) i = num_streams;
+    }
+    first[num_shards] = num_streams;
+    return BROTLIG_OK;
+}
+
+namespace {
+
+// rendezvous of the per-device host threads (C++17 has no std::barrier)
+struct Rendezvous {
+    std::mutex m; std::condition_variable cv; uint32_t waiting = 0, generation = 0; const uint32_t n;
+    bool disabled = false;          // set when not every member could be started: nobody waits any more
+    explicit Rendezvous(uint32_t count) : n(count) {}
+    void arrive()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        if (disabled) return;
+        const uint32_t gen = generation;
+        if (++waiting == n) { waiting = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lock, [&] { return generation != gen || disabled; });
+    }
+    void disable() { std::lock_guard<std::mutex> lock(m); disabled = true; cv.notify_all(); }
+};
+
+void run_shard(BrotligDeviceBatch* b, uint32_t warmup, uint32_t steps, Rendezvous* rv)
+{
+    b->kernel_ms = 0.0; b->wall_ms = 0.0;
+    BROTLIG_ERROR err = BROTLIG_OK;
+    hipStream_t s = static_cast<hipStream_t>(b->hip_stream);
+    std::vector<Event> ev(2 * (size_t)steps);
+    DecodeArgs a{};
+    do {
+        if (!b->d_in || !b->d_out || !b->d_streams || !b->d_workspace || b->num_streams == 0u ||
+            b->workspace_bytes < workspace_bytes(b->num_streams)) { err = BROTLIG_ERROR_GENERIC; break; }
+        if (hipSetDevice(b->device) != hipSuccess) { err = BROTLIG_ERROR_GENERIC; break; }
+        a = make_args(b->d_in, b->in_bytes, b->d_out, b->out_bytes, b->d_streams, b->num_streams, b->d_workspace,
+                      (size_t)b->workspace_bytes, b->d_scratch);
+        for (auto& e : ev) if (e.create() != hipSuccess) err = BROTLIG_ERROR_GENERIC;
+        for (uint32_t i = 0; i < warmup && err == BROTLIG_OK; ++i) err = enqueue(a, s, nullptr, nullptr);
+        if (err == BROTLIG_OK && hipStreamSynchronize(s) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
+    } while (false);
+    rv->arrive();                                                       // every device starts its timed passes together
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < steps && err == BROTLIG_OK; ++i) err = enqueue(a, s, ev[2 * i].e, ev[2 * i + 1].e);
+    if (err == BROTLIG_OK) err = BrotligDecodeBatchStatus(b->d_workspace, s);      // waits for the stream
+    b->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (err == BROTLIG_OK) {
+        double sum = 0.0;
+        for (uint32_t i = 0; i < steps; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev[2 * i].e, ev[2 * i + 1].e) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
+            sum += ms;
+        }
+        b->kernel_ms = steps ? sum / steps : 0.0;
+    }
+    b->result = (int32_t)err;
+    rv->arrive();
+}
+
+}  // namespace
+
+extern "C" BROTLIG_ERROR BrotligDecodeBatchMultiDevice(BrotligDeviceBatch* shards, uint32_t num_shards, uint32_t struct_bytes,
+                                                       uint32_t warmup, uint32_t steps, double* max_kernel_ms, double* max_wall_ms)
+{
+    if (!shards || num_shards == 0u || num_shards > 64u || steps == 0u || struct_bytes != sizeof(BrotligDeviceBatch)) return BROTLIG_ERROR_GENERIC;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    try {
+        Rendezvous rv(num_shards);
+        std::vector<std::thread> pool;
+        pool.reserve(num_shards);
+        uint32_t started = 0;
+        try {
+            for (uint32_t g = 1; g < num_shards; ++g) { pool.emplace_back(run_shard, shards + g, warmup, steps, &rv); ++started; }
+        } catch (const std::system_error&) {
+            rv.disable();           // a rendezvous short of members would never open: the shards without a thread of their
+                                    // own run on this thread, in turn, and nobody waits for anybody
+        }
+        run_shard(shards, warmup, steps, &rv);                          // shard 0 on the calling thread
+        for (uint32_t g = started + 1u; g < num_shards; ++g) run_shard(shards + g, warmup, steps, &rv);
+        for (auto& t : pool) t.join();
+    } catch (...) { (void)hipSetDevice(prev); return BROTLIG_ERROR_GENERIC; }
+    (void)hipSetDevice(prev);
+    BROTLIG_ERROR first_err = BROTLIG_OK;
+    double mk = 0.0, mw = 0.0;
+    for (uint32_t g = 0; g < num_shards; ++g) {
+        if (shards[g].result != BROTLIG_OK && first_err == BROTLIG_OK) first_err = (BROTLIG_ERROR)shards[g].result;
+        mk = shards[g].kernel_ms > mk ? shards[g].kernel_ms : mk;
+        mw = shards[g].wall_ms > mw ? shards[g].wall_ms : mw;
+    }
+    if (max_kernel_ms) *max_kernel_ms = mk;
+    if (max_wall_ms) *max_wall_ms = mw;
+    return first_err;
 }
 
 static uint32_t mx_other(const uint32_t* v, uint32_t base)     // maximum over the other half's 32 values
@@ -309,5 +507,6 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     return BROTLIG_OK;
 }
 
+extern "C" uint32_t BrotligAbiVersion(void) { return BROTLIG_AMD_ABI_VERSION; }
 extern "C" uint32_t BrotligKernelLdsBytes(void) { return (uint32_t)sizeof(WaveLds); }
 extern "C" uint32_t BrotligKernelGridSize(void) { Grids g; return grid_sizes(&g) == BROTLIG_OK ? (uint32_t)g.decode : 0u; }

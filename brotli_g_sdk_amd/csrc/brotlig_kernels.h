@@ -508,7 +508,9 @@ __device__ __forceinline__ uint32_t table_sym(const TableRef& t, uint32_t i)
     if (t.alphabet == kLitAlphabet) return (uint32_t)reinterpret_cast<const uint8_t*>(t.sorted)[i];
     const uint32_t cap = sym_cap(t.alphabet);
     if (i < cap) return sorted_get(t.sorted, i);
-    return (uint32_t)t.far_syms[far_slot(t.alphabet) + (i - cap)] & 0x3FFu;     // (same value range as the packed fields)
+    // a rank the page's code never assigned (incomplete or damaged code) reads whatever an earlier page left in the slot:
+    // held inside the alphabet, so that what a damaged page decodes to does not depend on the workspace's history
+    return min_u32((uint32_t)t.far_syms[far_slot(t.alphabet) + (i - cap)] & 0x3FFu, t.alphabet - 1u);
 }
 __device__ __forceinline__ void table_set_sym(const TableRef& t, uint32_t i, uint32_t sym)   // packed words pre-zeroed
 {
@@ -557,8 +559,10 @@ __device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitRe
 // -------------------------------------------------------------------------------------------
 // Prefix-code description -> decode tables (format: SURVEY.md A.5; reference reader:
 // src/decoder/BrotligHuffmanTable.cpp:73-205).  Runs for both halves at once; `live` says
-// whether this half has a compressed page.
-__device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br, bool live, uint32_t sl)
+// whether this half has a compressed page.  Returns false for a description the format does not define (the page
+// is then rejected): a `simple` code of one symbol, for which the reference indexes FixedCodelengths[-1]
+// (BrotligHuffmanTable.cpp:103); DecodeCPU (csrc/brotlig_cpu.cpp) rejects the same.
+__device__ inline bool build_table(const TableRef& t, PageLds& L, BitReader& br, bool live, uint32_t sl)
 {
     const uint32_t A = t.alphabet;
     const uint32_t maxbits = bit_width_u32(A - 1u);
@@ -576,6 +580,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
 
     // -- trivial / simple: up to 4 symbols, symbol k from sub-stream k
     const uint32_t nsym = is_trivial ? 1u : ((hdr >> 2) & 3u) + 1u;
+    const bool defined = !(is_simple && nsym < 2u);
     const uint32_t tree_select = (hdr >> 4) & 1u;
     uint32_t mysym = 0;
     if ((is_trivial || is_simple) && sl < nsym) mysym = br.read(maxbits);
@@ -727,6 +732,7 @@ __device__ inline void build_table(const TableRef& t, PageLds& L, BitReader& br,
         }
     }
     wave::sync();
+    return defined;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -920,6 +926,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
                 clk.lap(kPhSetup);
                 // one copy of the table builder in the instruction stream, run three times (ICP, distance, literal):
                 // inlined three times it was most of the kernel's code size, beyond what the instruction cache holds
+                bool tables_ok = true;
 #pragma nounroll
                 for (uint32_t k = 0; k < 3u; ++k) {
                     const TableRef t{k == 0u ? L.lut_icp : k == 1u ? L.lut_dist : L.lut_lit,
@@ -927,13 +934,17 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
                                      L.limit[k], L.first_offs[k],
                                      k == 0u ? kIcpAlphabet : k == 1u ? kDistAlphabet : kLitAlphabet,
                                      k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit, far_syms};
-                    build_table(t, L, br, start, sl);
+                    const bool ok = build_table(t, L, br, start, sl);
+                    tables_ok = tables_ok && ok;
                 }
                 if (start) {
                     ring0 = 4; ring1 = 11; ring2 = 15; ring3 = 16; ring_cnt = 0;
                     out_pos = 0; prev_tail = 0; carry_head = 0; flushed = 0; bad = false;
                     view.win_base = 0u;
                     live = true;
+                    // an undefined code description rejects the page: with the page "full" its first round is refused
+                    // (or is a bare sentinel), nothing is assembled or flushed, and the page ends with `bad` set
+                    if (!tables_ok) { bad = true; out_pos = flushed = job.out_size; }
                 }
                 clk.lap(kPhTables);
             }

@@ -5,11 +5,15 @@ torch.distributed (RCCL on ROCm, gloo in the CPU tests) is used only for the bar
 timing/byte-count reductions of the benchmark."""
 
 
-def stream_indices(n_streams, world, rank):
-    """Contiguous, balanced slice of range(n_streams) owned by `rank`."""
-    base, rem = divmod(n_streams, world)
-    start = rank * base + min(rank, rem)
-    return list(range(start, start + base + (1 if rank < rem else 0)))
+def stream_indices(n_streams, world, rank, in_sizes=None):
+    """Contiguous slice of range(n_streams) owned by `rank`: the run BrotligShardPlan (include/brotlig_amd.h) gives it --
+    runs balanced by COMPRESSED bytes (`in_sizes`, one per stream; SURVEY.md 8(e): "balance by compressed bytes, not
+    page count"), streams never split.  Without sizes every stream weighs the same."""
+    from . import api
+    sizes = [1] * n_streams if in_sizes is None else [int(x) for x in in_sizes]
+    assert len(sizes) == n_streams
+    first = api.ShardPlan(sizes, world)
+    return list(range(first[rank], first[rank + 1]))
 
 
 def _reduce(value, op_name):
@@ -64,11 +68,11 @@ def scatter_streams(streams, src=0):
         sizes.copy_(torch.tensor([len(s) for s in streams], dtype=torch.int64))
     dist.broadcast(sizes, src)
     sizes = sizes.cpu().tolist()
-    mine = stream_indices(len(sizes), world, rank)
+    mine = stream_indices(len(sizes), world, rank, sizes)
     if rank == src:
         ops, keep = [], []
         for r in range(world):
-            idx = stream_indices(len(sizes), world, r)
+            idx = stream_indices(len(sizes), world, r, sizes)
             if r == src or not idx:
                 continue
             buf = torch.from_numpy(np.concatenate([np.asarray(streams[i], dtype=np.uint8) for i in idx])).to(dev)

@@ -17,6 +17,20 @@
 extern "C" {
 #endif
 
+/* ABI version of the device-pointer batch interface.  Version 3 (round 3): 32-byte BrotligStreamDesc (was 16), d_in must
+ * extend 16 bytes past in_bytes, the workspace holds the per-wavefront symbol slots (+15 MiB).  The entry points whose
+ * contract changed carry the version in their SYMBOL names (the macros below), so a caller built against an older header
+ * fails to link instead of passing descriptors of the wrong stride; BrotligAbiVersion() answers at run time (dlopen users). */
+#define BROTLIG_AMD_ABI_VERSION 3
+#define BrotligDecodeWorkspaceSize      BrotligDecodeWorkspaceSize_v3
+#define BrotligDecodeWorkspaceSizeFor   BrotligDecodeWorkspaceSizeFor_v3
+#define BrotligDecodeBatchDevice        BrotligDecodeBatchDevice_v3
+#define BrotligDecodeBatchStatus        BrotligDecodeBatchStatus_v3
+#define BrotligDecodeBatchTimed         BrotligDecodeBatchTimed_v3
+#define BrotligDecodePhaseProfile       BrotligDecodePhaseProfile_v3
+#define BrotligDecodeBatchMultiDevice   BrotligDecodeBatchMultiDevice_v3
+uint32_t BrotligAbiVersion(void);
+
 /* inc/common/BrotligCommon.h:50-68 -- same enumerators, same numeric values */
 typedef enum BROTLIG_ERROR {
     BROTLIG_OK = 0,
@@ -57,6 +71,16 @@ uint32_t DecompressedSize(uint8_t* src);
  * throws std::exception there) and for pages that fail a bounds check. */
 BROTLIG_ERROR DecodeGPU(int useWarpDevice, uint32_t input_size, const uint8_t* input,
                         uint32_t* output_size, uint8_t* output, double* time_ms);
+
+/* Optional reusable context for DecodeGPU ("a reusable context object is allowed for HIP module / scratch
+ * reuse but must be optional"): device buffers that only grow, one stream, two events.  DecodeGPU itself stays stateless
+ * (it builds a context for the length of the call: five hipMalloc / hipFree pairs, which dominate small assets).
+ * `device` < 0: the calling thread's current device.  One context per host thread. */
+typedef struct BrotligContext BrotligContext;
+BROTLIG_ERROR BrotligContextCreate(int device, BrotligContext** out);
+void BrotligContextDestroy(BrotligContext* context);
+BROTLIG_ERROR BrotligContextDecodeGPU(BrotligContext* context, uint32_t input_size, const uint8_t* input,
+                                      uint32_t* output_size, uint8_t* output, double* time_ms);
 
 /* ---- device-pointer batch interface -------------------------------------------------------
  * Replaces the kernel-level contract of the reference shader: three buffers (input = whole
@@ -117,6 +141,42 @@ BROTLIG_ERROR BrotligDecodeBatchTimed(const void* d_in, uint64_t in_bytes, void*
                                       void* d_workspace, size_t workspace_bytes, void* d_scratch,
                                       void* hip_stream, uint32_t warmup, uint32_t steps,
                                       double* total_ms, double* decode_kernel_ms);
+
+/* ---- multi-device fan-out ---------------------------------------------------------------
+ * Streams are independent, so a batch shards over the GPUs of a node with no exchange between them.  The reference's
+ * analogues: pages fanned out over host threads (src/BrotligDecoder.cpp:356-375) and streams over the shader's queue
+ * (src/decoder/BrotliGCompute.hlsl:1757-1881).
+ *
+ * BrotligShardPlan cuts the stream list into `num_shards` contiguous runs: first[g] .. first[g+1]-1 is shard g
+ * (first has num_shards + 1 entries).  The cut minimises the largest run's COMPRESSED bytes (`in_sizes`, one per
+ * stream) -- decode cost follows compressed size, not the 64 KiB of output per page -- and leaves no shard empty while
+ * streams remain.  Streams are never split (a pre-conditioned stream's pages scatter over its whole texture).  Pure
+ * host arithmetic: needs no device. */
+BROTLIG_ERROR BrotligShardPlan(const uint64_t* in_sizes, uint32_t num_streams, uint32_t num_shards, uint32_t* first);
+
+/* One shard: the arguments of BrotligDecodeBatchDevice for the streams placed on `device`, plus results. */
+typedef struct BrotligDeviceBatch {
+    int32_t  device;                    /* HIP device ordinal */
+    uint32_t num_streams;
+    const void* d_in;   uint64_t in_bytes;
+    void* d_out;        uint64_t out_bytes;
+    const BrotligStreamDesc* d_streams;
+    void* d_workspace;  uint64_t workspace_bytes;
+    void* d_scratch;
+    void* hip_stream;                   /* a stream of `device` (NULL: its default stream) */
+    int32_t  result;                    /* out: BROTLIG_ERROR of this shard (enqueue + batch status) */
+    uint32_t reserved;
+    double   kernel_ms;                 /* out: average decode-kernel time of the timed passes (HIP events on hip_stream) */
+    double   wall_ms;                   /* out: host clock from the common start to this shard's completion, all timed passes */
+} BrotligDeviceBatch;
+
+/* Decodes every shard, one host thread per shard (shard 0 on the calling thread), each thread on its shard's device:
+ * `warmup` untimed passes, a rendezvous, then `steps` (>= 1) timed passes and the shard's batch status.  Shards may name
+ * the same device (they then share it; use distinct hip_streams).  `struct_bytes` = sizeof(BrotligDeviceBatch).
+ * *max_kernel_ms / *max_wall_ms (may be NULL): maxima over the shards -- the time of the whole job is the slowest device's.
+ * Returns the first shard error, BROTLIG_OK if none.  The calling thread's current device is restored. */
+BROTLIG_ERROR BrotligDecodeBatchMultiDevice(BrotligDeviceBatch* shards, uint32_t num_shards, uint32_t struct_bytes,
+                                            uint32_t warmup, uint32_t steps, double* max_kernel_ms, double* max_wall_ms);
 
 /* Device self-test of the wave primitives the kernels rely on (DPP scan vs shuffle scan,
  * half-wave ballot / shuffle / max).  Returns BROTLIG_OK when they agree. */

@@ -14,12 +14,30 @@ extern "C" {
  *   inc/BrotligDecoder.h:33, src/BrotligDecoder.cpp:495-519 (-> :426-493).
  * Host pointers.  *output_size = capacity of `output` on entry (for a pre-conditioned stream exactly the texture
  * size, src/BrotligDecoder.cpp:478), decompressed size on return.  Pages are decoded by one thread per hardware
- * thread, at most 32 (created per call; BrotligDecodeCPU takes up to the reference's 128, inc/common/BrotligConstants.h:90).  `feedbackProc`: the reference's callback takes a std::string and cannot
- * cross a C boundary; pass NULL (anything else is ignored).
+ * thread, at most 32 (created per call; BrotligDecodeCPU takes up to the reference's 128, inc/common/BrotligConstants.h:90).  `feedbackProc`: the reference's
+ * BROTLIG_Feedback_Proc is `bool (*)(BROTLIG_MESSAGE_TYPE, std::string)` (inc/common/BrotligCommon.h:92) -- a C++ class by value,
+ * which cannot cross a C boundary; this entry therefore only takes NULL there (a non-NULL pointer returns
+ * BROTLIG_ERROR_GENERIC instead of being called with the wrong convention).  Progress and abort: BrotligDecodeCPUWithFeedback.
+ * The whole of `output` (*output_size bytes on entry) is zeroed first, as src/BrotligDecoder.cpp:448 does.
  * Errors: BROTLIG_ERROR_CORRUPT_STREAM (magic), BROTLIG_ERROR_INCORRECT_STREAM_FORMAT (id != 5) as
  * src/BrotligDecoder.cpp:437-446; BROTLIG_ERROR_GENERIC for a page that fails a bounds check or an output
  * buffer of the wrong size (undefined behaviour in the reference).  Only bytes of `src` inside input_size are read. */
 BROTLIG_ERROR DecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, void* feedbackProc);
+
+/* inc/common/BrotligCommon.h:70-73 */
+typedef enum BROTLIG_MESSAGE_TYPE { BROTLIG_PROGRESS = 0, BROTLIG_WARNING = 1 } BROTLIG_MESSAGE_TYPE;
+
+/* C form of BROTLIG_Feedback_Proc (inc/common/BrotligCommon.h:92): message as text, plus a user pointer.  Non-zero = stop. */
+typedef int (*BrotligFeedbackProc)(int type /* BROTLIG_MESSAGE_TYPE */, const char* message, void* user);
+
+/* DecodeCPU with the reference's feedback semantics (src/BrotligDecoder.cpp:318-325): after every page `feedback` (may be
+ * NULL) is called FROM THE WORKER THREAD that decoded it with (BROTLIG_PROGRESS, "<100 * page / pages as %f>", user); a
+ * non-zero return stops all workers and the call returns BROTLIG_ABORTED with `output` partly written and *output_size
+ * untouched.  (The reference stops the same way but still returns BROTLIG_OK, and its multi-threaded build never hands the
+ * callback to its workers, src/BrotligDecoder.cpp:348-356 -- BROTLIG_ABORTED, inc/common/BrotligCommon.h:52, is what the
+ * enumerator is for.)  `workers` as in BrotligDecodeCPU. */
+BROTLIG_ERROR BrotligDecodeCPUWithFeedback(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output,
+                                           uint32_t workers, BrotligFeedbackProc feedback, void* user);
 
 /* The same with an explicit thread count (0 = DecodeCPU's default; never more than one per page, at most 128). */
 BROTLIG_ERROR BrotligDecodeCPU(uint32_t input_size, const uint8_t* src, uint32_t* output_size, uint8_t* output, uint32_t workers);

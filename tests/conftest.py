@@ -29,9 +29,21 @@ def pytest_collection_modifyitems(config, items):
     gpu_items = [it for it in items if it.get_closest_marker("gpu") is not None]
     if not gpu_items or _hip_device_usable():
         return
+    if os.environ.get("BROTLIG_REQUIRE_GPU") == "1":
+        # on the GPU box a missing device must not pass as a green run of skips
+        raise pytest.UsageError("BROTLIG_REQUIRE_GPU=1 but no usable HIP device: the gpu-marked tests cannot run")
+    config._brotlig_gpu_skipped = len(gpu_items)
     skip = pytest.mark.skip(reason="no usable HIP device (gpu tests run on the MI355X box)")
     for it in gpu_items:
         it.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    n = getattr(config, "_brotlig_gpu_skipped", 0)
+    if n:
+        terminalreporter.write_sep("=", f"{n} gpu-marked tests SKIPPED: no HIP device here -- the HIP kernels were exercised by the CPU "
+                                        "simulator only (tests/sim); run `pytest -m gpu` on the MI355X box (BROTLIG_REQUIRE_GPU=1 makes "
+                                        "a missing device an error)", yellow=True, bold=True)
 
 
 @pytest.fixture(scope="session")

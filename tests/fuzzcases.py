@@ -124,3 +124,30 @@ def corrupt(stream, seed):
         if first + 8 < len(s):
             s[first + int(rng.integers(0, 8))] ^= np.uint8(1 << int(rng.integers(0, 8)))
     return s, kind
+
+
+def _first_page_substream0(stream):
+    """Byte offset (in the stream) of sub-stream 0 of the first page of a plain single-page stream."""
+    bw = lambda x: int(x).bit_length()
+    npages = int(stream[2]) | (int(stream[3]) << 8)
+    first = 8 + 4 * npages
+    size = int.from_bytes(stream[8:12].tobytes(), "little") if npages == 1 else int.from_bytes(stream[12:16].tobytes(), "little")
+    h = int.from_bytes(stream[first:first + 8].tobytes(), "little")
+    base_bits, dsize_bits = bw((size + 31) // 32), bw(bw(size - 1))
+    delta_bits = (h >> (8 + base_bits)) & ((1 << dsize_bits) - 1)
+    return first + ((8 + base_bits + dsize_bits + 32 * delta_bits + 31) // 32) * 4
+
+
+def simple_code_one_symbol():
+    """(stream, output capacity): a valid stream whose first prefix-code description (ICP) is `simple`, with its
+    NSYM field patched to 0 -- one symbol, which the format does not define (BrotligHuffmanTable.cpp:103 indexes
+    FixedCodelengths[-1])."""
+    for n in (40000, 65536, 20000, 3000):
+        for data in (np.zeros(n, np.uint8), np.tile(np.arange(7, dtype=np.uint8), n // 7 + 1)[:n]):
+            s = E.encode(data)
+            at = _first_page_substream0(s)
+            if int(s[at]) & 3 == 1:
+                bad = s.copy()
+                bad[at] &= np.uint8(0xF3)                           # NSYM - 1 field (bits 2..3) <- 0
+                return bad, len(data)
+    raise AssertionError("no input produced a simple ICP code")

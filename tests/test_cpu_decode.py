@@ -32,7 +32,7 @@ def guarded_decode(stream, cap, workers=None):
 
 def test_library_exports_the_declared_symbols():
     so = ctypes.CDLL(_build.build_cpu())
-    for n in ("DecodeCPU", "BrotligDecodeCPU", "DecompressedSize"):
+    for n in ("DecodeCPU", "BrotligDecodeCPU", "BrotligDecodeCPUWithFeedback", "DecompressedSize"):
         assert hasattr(so, n), n
     # and the GPU library stays GPU-only
     hip = ctypes.CDLL(_build.build_hip())
@@ -128,3 +128,68 @@ def test_big_batch_worker_counts_agree():
     for workers in (1, 2, 7, 64, None):
         rc, out = cpu.DecodeCPU(stream, workers=workers)
         assert rc == 0 and np.array_equal(out, data), workers
+
+
+def test_feedback_reports_every_page_and_can_abort():
+    """src/BrotligDecoder.cpp:318-325: one BROTLIG_PROGRESS message per page, `100 * page / pages` as text; a true return
+    stops the decode.  Through the C twin (the reference's std::string callback cannot cross a C boundary)."""
+    import threading
+    data = D.mixed(24 * 65536 + 100, seed=9)
+    stream = E.encode(data)
+    pages = 25
+    seen, lock = [], threading.Lock()
+
+    def progress(kind, msg):
+        with lock:
+            seen.append((kind, float(msg)))
+        return False
+    for workers in (1, 4):
+        seen.clear()
+        rc, out = cpu.DecodeCPU(stream, workers=workers, feedbackProc=progress)
+        assert rc == 0 and np.array_equal(out, data)
+        assert len(seen) == pages and all(k == cpu.BROTLIG_PROGRESS for k, _ in seen)
+        want = sorted(float("%f" % (100.0 * np.float32(i) / np.float32(pages))) for i in range(pages))
+        assert sorted(v for _, v in seen) == pytest.approx(want, abs=1e-4)
+
+    calls = []
+
+    def stop_at_third(kind, msg):
+        with lock:
+            calls.append(msg)
+            return len(calls) >= 3
+    rc, out = cpu.DecodeCPU(stream, workers=1, feedbackProc=stop_at_third)
+    assert rc == cpu.BROTLIG_ABORTED and len(out) == 0 and len(calls) == 3
+    calls.clear()
+    rc, _ = cpu.DecodeCPU(stream, workers=4, feedbackProc=stop_at_third)
+    assert rc == cpu.BROTLIG_ABORTED and 3 <= len(calls) <= 3 + 4           # workers in flight finish their page
+
+
+def test_reference_named_entry_refuses_a_cxx_callback_pointer():
+    data = D.text(70000, 2)
+    s = E.encode(data)
+    out = np.empty(len(data), np.uint8)
+    osz = ctypes.c_uint32(len(data))
+    rc = cpu.lib().DecodeCPU(len(s), s.ctypes.data, ctypes.byref(osz), out.ctypes.data, ctypes.c_void_p(0x1000))
+    assert rc == 16                                                 # BROTLIG_ERROR_GENERIC, nothing called
+    rc = cpu.lib().DecodeCPU(len(s), s.ctypes.data, ctypes.byref(osz), out.ctypes.data, None)
+    assert rc == 0 and np.array_equal(out, data)
+
+
+def test_whole_output_buffer_is_zeroed_like_the_reference():
+    """src/BrotligDecoder.cpp:448: memset(output, 0, *output_size) before any page is decoded."""
+    data = D.text(70000, 3)
+    s = E.encode(data)
+    cap = len(data) + 500
+    buf = np.full(cap, 0x77, np.uint8)
+    osz = ctypes.c_uint32(cap)
+    rc = cpu.lib().BrotligDecodeCPU(len(s), s.ctypes.data, ctypes.byref(osz), buf.ctypes.data, 1)
+    assert rc == 0 and osz.value == len(data) and np.array_equal(buf[:len(data)], data) and not buf[len(data):].any()
+
+
+def test_simple_code_with_one_symbol_is_rejected():
+    """A `simple` prefix code announcing one symbol (NSYM field 0) indexes FixedCodelengths[-1] in the reference
+    (BrotligHuffmanTable.cpp:103): undefined there, rejected here (and by the GPU kernel, tests/test_sim_decode.py)."""
+    from fuzzcases import simple_code_one_symbol
+    bad, cap = simple_code_one_symbol()
+    rc, _ = guarded_decode(bad, cap)
+    assert rc != 0

@@ -86,8 +86,7 @@ def _exchange_worker(rank, world, port, q):
     datas = [D.mixed(65536 + 1000 * k, 300 + k) for k in range(5)]
     streams = [E.encode(d) for d in datas] if rank == 0 else []          # the compressed data starts on rank 0 only
     mine = shard.scatter_streams(streams, src=0)
-    idx = shard.stream_indices(5, world, rank)
-    assert len(mine) == len(idx)
+    # (which rank gets which streams follows their compressed sizes: BrotligShardPlan; the gather below checks the cover)
     outs = []
     for s in mine:                                                       # the oracle stands in for the device here
         rc, out = oracle_decode(s)

@@ -292,3 +292,68 @@ def test_streamer_ring_overflow_keeps_results(api):
     with pytest.raises(api.BrotligError):                                   # two generations back: forgotten
         st.wait(tickets[0])
     st.close()
+
+
+def test_multi_device_entry_with_three_shards_on_the_one_device(api):
+    """BrotligDecodeBatchMultiDevice (include/brotlig_amd.h): the stream list cut by BrotligShardPlan (balanced by
+    compressed bytes), one BrotligDeviceBatch per shard, one host thread per shard.  The box has one device, so the
+    shards share it on streams of their own; a node with G devices runs the same call with device = 0..G-1."""
+    import torch
+    datas = [D.mixed(3 * 65536 + 11 * k, 500 + k) for k in range(5)] + [D.runs(6 * 65536, 9), D.random_bytes(2 * 65536, 3),
+                                                                        D.text(65536 + 77, 8), D.records(4 * 65536, 2)]
+    streams = [E.encode(d) for d in datas]
+    first = api.ShardPlan([len(s) for s in streams], 3)
+    assert first[0] == 0 and first[-1] == len(streams) and all(b > a for a, b in zip(first, first[1:]))
+    decs = [api.BatchDecoder(streams[a:b]) for a, b in zip(first, first[1:])]
+    side = [torch.cuda.Stream() for _ in decs]
+    for d in decs:
+        d.poison_output()
+    torch.cuda.synchronize()
+    mk, mw, per = api.DecodeBatchMultiDevice(decs, warmup=1, steps=2, streams=[s.cuda_stream for s in side])
+    assert all(r == 0 for r, _, _ in per) and mk == max(k for _, k, _ in per) > 0.0 and mw >= mk * 2 * 0.5
+    torch.cuda.synchronize()
+    k = 0
+    for d in decs:
+        for i in range(d.n):
+            assert np.array_equal(d.output(i), datas[k]), k
+            k += 1
+    assert k == len(datas)
+    # a damaged stream in one shard is that shard's result, and the call's
+    bad = streams[0].copy(); bad[1] ^= 1
+    decs2 = [api.BatchDecoder([bad]), api.BatchDecoder([streams[1]])]
+    with pytest.raises(api.BrotligError):
+        api.DecodeBatchMultiDevice(decs2)
+    torch.cuda.synchronize()
+    assert np.array_equal(decs2[1].output(0), datas[1])
+
+
+def test_context_decodes_assets_of_growing_and_shrinking_size(api):
+    """BrotligContext: DecodeGPU with buffers kept between calls (they only grow)."""
+    ctx = api.Context()
+    for n, seed in ((70000, 1), (9 * 65536 + 5, 2), (100, 3), (3 * 65536, 4)):
+        data = D.mixed(n, seed)
+        out, ms = ctx.DecodeGPU(E.encode(data))
+        assert np.array_equal(out, data) and ms > 0.0
+    tex = D.bc_texture(1, 40, 24, seed=5)
+    s = E.encode(tex, precondition=dict(format=1, width_blocks=40, height_blocks=24, swizzle=True, delta=True))
+    out, _ = ctx.DecodeGPU(s, output_size=len(tex))
+    rc, ref = oracle_decode(s, out_size=len(tex))
+    assert rc == 0 and np.array_equal(out, ref)
+    bad = E.encode(D.text(70000, 1)); bad[1] ^= 1
+    with pytest.raises(api.BrotligError):
+        ctx.DecodeGPU(bad)
+    out, _ = ctx.DecodeGPU(E.encode(D.text(70000, 1)))              # still usable after an error
+    assert np.array_equal(out, D.text(70000, 1))
+    ctx.close()
+
+
+def test_simple_code_with_one_symbol_rejects_the_page_on_device(api):
+    """Same case as tests/test_sim_decode.py / test_cpu_decode.py: undefined in the format, rejected everywhere."""
+    from fuzzcases import simple_code_one_symbol
+    bad, cap = simple_code_one_symbol()
+    good = D.text(70000, 4)
+    dec = api.BatchDecoder([bad, E.encode(good)], out_sizes=[cap, len(good)])
+    dec.poison_output()
+    with pytest.raises(api.BrotligError):
+        dec.decode()
+    assert np.all(dec.output(0) == 0xCD) and np.array_equal(dec.output(1), good)

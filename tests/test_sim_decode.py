@@ -215,3 +215,16 @@ def test_sim_source_forwarding_variant(sim_forwarding):
     assert status == 0
     for o, r in zip(outs, refs):
         assert np.array_equal(o, r)
+
+
+def test_sim_simple_code_with_one_symbol_rejects_the_page(sim):
+    """NSYM field 0 of a `simple` prefix code is undefined in the format (the reference indexes FixedCodelengths[-1],
+    BrotligHuffmanTable.cpp:103): the kernel rejects the page -- status set, not one byte of it written -- like
+    DecodeCPU (tests/test_cpu_decode.py), and a valid stream in the same launch is untouched by it."""
+    from fuzzcases import simple_code_one_symbol
+    bad, cap = simple_code_one_symbol()
+    good_data = D.text(70000, 4)
+    outs, status = run_batch(sim, [bad, E.encode(good_data)], [cap, len(good_data)])
+    assert status & 2                                               # kStatusBadPage
+    assert np.all(outs[0] == 0xCD)                                  # nothing of the rejected page reached the output
+    assert np.array_equal(outs[1], good_data)
