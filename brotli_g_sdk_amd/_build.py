@@ -41,7 +41,7 @@ def build_cpu(force=False):
 
 
 def hip_sources():
-    names = ["brotlig_hip.hip", "brotlig_streamer.hip", "brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h"]
+    names = ["brotlig_hip.hip", "brotlig_streamer.hip", "brotlig_kernels.h", "brotlig_split_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h"]
     return [os.path.join(CSRC, n) for n in names] + [os.path.join(ROOT, "include", "brotlig_amd.h")]
 
 

@@ -19,6 +19,7 @@
 
 #include "brotlig_amd.h"
 #include "brotlig_kernels.h"
+#include "brotlig_split_kernels.h"
 
 using namespace brotlig;
 
@@ -36,10 +37,16 @@ static_assert(sizeof(BrotligStreamDesc) == sizeof(StreamDesc), "descriptor layou
 constexpr size_t kWsHeaderWords = 64;
 size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 1023u) & ~(size_t)1023u; }
 // per-half slots for the prefix-code symbols that overflow the LDS arrays, for every workgroup of the largest decode grid
-constexpr uint32_t kMaxDecodeGrid = 4096;
+constexpr uint32_t kMaxDecodeGrid = 8192;
 constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
 size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
 size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
+// Split path (brotlig_split_kernels.h; A/B experiment, switched on with BROTLIG_SPLIT=1): per page one slot of
+// (cap + 1) command words and a literal array of a page plus slack, and two header words.
+bool split_enabled() { static const bool on = [] { const char* e = getenv("BROTLIG_SPLIT"); return e && atoi(e) != 0; }(); return on; }
+uint32_t split_cmd_cap() { static const uint32_t c = [] { const char* e = getenv("BROTLIG_SPLIT_CAP"); return e ? (uint32_t)atoi(e) : 16384u; }(); return c; }
+constexpr uint32_t kLitStride = kMaxPageSize + 64u;
+size_t split_slot_bytes() { return ((size_t)split_cmd_cap() + 1u) * 8u + kLitStride + 8u; }
 // every page is at least 32 KiB of output, and every stream's output region is whole pages
 uint64_t max_pages(uint32_t n, uint64_t out_bytes) { return out_bytes / kMinPageSize + n; }
 // Below this many pages the schedule is not worth its two extra launches (about two pages per half-wave).
@@ -47,7 +54,7 @@ constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
 
 // Launch geometry per device (CU count x occupancy of the decode kernel), looked up once per device;
 // host threads driving different devices (or the same one) may arrive here concurrently.
-struct Grids { int decode = 0, decond = 1024, order = 1024; };
+struct Grids { int decode = 0, decond = 1024, order = 1024, entropy = 0, assemble = 0; };
 constexpr int kMaxDevices = 64;
 std::mutex g_grid_mutex;
 Grids g_grids[kMaxDevices];
@@ -73,6 +80,20 @@ BROTLIG_ERROR grid_sizes(Grids* out)
         g.decond = cus * 8;
         g.order = cus * 4;
         g.decode = cus * per_cu < (int)kMaxDecodeGrid ? cus * per_cu : (int)kMaxDecodeGrid;
+        auto grid_of = [&](const void* fn, const char* env, int* out) -> BROTLIG_ERROR {
+            int n = 0;
+            hipFuncAttributes a{};
+            HIP_OK(hipFuncGetAttributes(&a, fn));
+            HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, 0));
+            const int gr = (int)((a.sharedSizeBytes + 1279u) / 1280u);
+            if (gr > 0 && n > 128 / gr) n = 128 / gr;
+            if (const char* e = getenv(env)) n = atoi(e);
+            if (n < 1) n = 1;
+            *out = cus * n < (int)kMaxDecodeGrid ? cus * n : (int)kMaxDecodeGrid;
+            return BROTLIG_OK;
+        };
+        if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_entropy_kernel), "BROTLIG_E_PER_CU", &g.entropy)) return e;
+        if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_kernel), "BROTLIG_L_PER_CU", &g.assemble)) return e;
     }
     *out = g;
     return BROTLIG_OK;
@@ -103,9 +124,23 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
     a.far_syms = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_ws) + far_syms_offset(n));
     const size_t base = workspace_bytes(n);
     const uint64_t room = ws_bytes > base ? (ws_bytes - base) / 4u : 0u;
+    size_t used = base;
     if (out_bytes >= kOrderMinOutBytes && room >= max_pages(n, out_bytes)) {
         a.order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_ws) + base);
-        a.order_cap = (uint32_t)(room > 0xFFFFFFFFull ? 0xFFFFFFFFull : room);
+        a.order_cap = (uint32_t)max_pages(n, out_bytes);
+        used = base + 4u * max_pages(n, out_bytes);
+    }
+    a.work_counter2 = ws + 4;
+    if (split_enabled()) {                                              // slots behind the schedule, if the workspace has them
+        const uint64_t pages = max_pages(n, out_bytes);
+        used = (used + 255u) & ~(size_t)255u;
+        if (ws_bytes >= used + pages * split_slot_bytes()) {
+            uint8_t* p = static_cast<uint8_t*>(d_ws) + used;
+            a.cmd_cap = split_cmd_cap(); a.lit_stride = kLitStride;
+            a.cmds = reinterpret_cast<uint64_t*>(p); p += pages * ((size_t)a.cmd_cap + 1u) * 8u;
+            a.lits = p; p += pages * (size_t)kLitStride;
+            a.slot_hdr = reinterpret_cast<uint32_t*>(p);
+        }
     }
     return a;
 }
@@ -125,7 +160,12 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     if (const char* e = getenv("BROTLIG_POLICY"))       // diagnostics: pin the pairing policy (quarters of a page a free half waits)
         HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), atoi(e), 1, s));
     if (k0) HIP_OK(hipEventRecord(k0, s));
-    hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, s, a);
+    if (a.cmds != nullptr) {                                            // split path: entropy decode, then assembly
+        hipLaunchKernelGGL(brotlig_entropy_kernel, dim3(g.entropy), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(brotlig_assemble_kernel, dim3(g.assemble), dim3(64), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, s, a);
+    }
     if (k1) HIP_OK(hipEventRecord(k1, s));
     {   // streams over y, each stream's tiles over x; about 8 workgroups of 256 per CU in total
         const unsigned gy = a.num_streams < 32u ? a.num_streams : 32u;
@@ -162,7 +202,9 @@ extern "C" uint32_t DecompressedSize(uint8_t* src)
 extern "C" size_t BrotligDecodeWorkspaceSize(uint32_t num_streams) { return workspace_bytes(num_streams); }
 extern "C" size_t BrotligDecodeWorkspaceSizeFor(uint32_t num_streams, uint64_t out_bytes)
 {
-    return workspace_bytes(num_streams) + (size_t)(4u * max_pages(num_streams, out_bytes));
+    size_t b = workspace_bytes(num_streams) + (size_t)(4u * max_pages(num_streams, out_bytes));
+    if (split_enabled()) b = ((b + 255u) & ~(size_t)255u) + (size_t)max_pages(num_streams, out_bytes) * split_slot_bytes();
+    return b;
 }
 
 extern "C" BROTLIG_ERROR BrotligDecodeBatchDevice(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,

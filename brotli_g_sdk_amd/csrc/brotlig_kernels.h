@@ -82,6 +82,13 @@ struct DecodeArgs {
     uint16_t* far_syms;     // [workgroups of the decode grid][2][kFarSymStride] per 32-lane half: the ICP and distance symbols
                             // (canonical-code order) that do not fit the LDS arrays -- ranks kIcpSymCap.. and kDistSymCap..
     unsigned long long* prof;   // [kNumPhases] cycle sums, only written by the phase-timer instantiation
+    // split path (brotlig_split_kernels.h): the entropy kernel leaves every compressed page as a command array and a
+    // literal array in global memory, the assembly kernel builds the page from them.  Slots are indexed by global page index.
+    uint64_t* cmds;             // [pages][cmd_cap + 1] packed commands, then one terminal entry
+    uint8_t*  lits;             // [pages][lit_stride] literals in consumption order
+    uint32_t* slot_hdr;         // [pages][2]: number of commands, flags (kSlot*)
+    uint32_t  cmd_cap, lit_stride;
+    uint32_t* work_counter2;    // [1] page counter of the assembly kernel
 };
 
 // Phase timers (diagnostics build of the kernel only).
@@ -559,10 +566,10 @@ __device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitRe
 // -------------------------------------------------------------------------------------------
 // Prefix-code description -> decode tables (format: SURVEY.md A.5; reference reader:
 // src/decoder/BrotligHuffmanTable.cpp:73-205).  Runs for both halves at once; `live` says
-// whether this half has a compressed page.  Returns false for a description the format does not define (the page
+// whether this half has a compressed page; `codelens` = alphabet bytes of LDS for the code lengths.  Returns false for a description the format does not define (the page
 // is then rejected): a `simple` code of one symbol, for which the reference indexes FixedCodelengths[-1]
 // (BrotligHuffmanTable.cpp:103); DecodeCPU (csrc/brotlig_cpu.cpp) rejects the same.
-__device__ inline bool build_table(const TableRef& t, PageLds& L, BitReader& br, bool live, uint32_t sl)
+__device__ inline bool build_table(const TableRef& t, uint8_t* codelens, BitReader& br, bool live, uint32_t sl)
 {
     const uint32_t A = t.alphabet;
     const uint32_t maxbits = bit_width_u32(A - 1u);
@@ -641,7 +648,7 @@ __device__ inline bool build_table(const TableRef& t, PageLds& L, BitReader& br,
             else if (sym == 16u) value = before ? from_lane : prev_len;    // repeat previous *literal* length
             if (valid) {
                 const uint32_t end = min_u32(start + run, A);
-                for (uint32_t s = start; s < end; ++s) L.win[s] = (uint8_t)value;
+                for (uint32_t s = start; s < end; ++s) codelens[s] = (uint8_t)value;
             }
             produced = min_u32(A, produced + wave::half_sum(valid ? run : 0u));
             if (lit_mask) prev_len = last_lit;
@@ -657,7 +664,7 @@ __device__ inline bool build_table(const TableRef& t, PageLds& L, BitReader& br,
         if (is_complex && A != kLitAlphabet) for (uint32_t w = sl; w < (sym_cap(A) + 2u) / 3u; w += 32u) t.sorted[w] = 0u;
         wave::sync();
         if (is_complex)
-            for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = L.win[s] & 15u; if (l) cnt[l * 32u + sl]++; }
+            for (uint32_t s = b0; s < b1; ++s) { const uint32_t l = codelens[s] & 15u; if (l) cnt[l * 32u + sl]++; }
         wave::sync();
         uint32_t code = 0, off = 0, prev_count = 0;
         for (uint32_t l = 1; l < 16u; ++l) {
@@ -675,7 +682,7 @@ __device__ inline bool build_table(const TableRef& t, PageLds& L, BitReader& br,
         wave::sync();
         if (is_complex)
             for (uint32_t s = b0; s < b1; ++s) {
-                const uint32_t l = L.win[s] & 15u;
+                const uint32_t l = codelens[s] & 15u;
                 if (l) { const uint32_t p = cnt[l * 32u + sl]++; table_set_sym(t, min_u32(p, A - 1u), s); }
             }
         // symbols beyond the LDS arrays went to global memory: stores first, then the reads below and in the rounds
@@ -746,6 +753,7 @@ struct PageJob {
     uint32_t page_size;
     uint32_t page_off;      // offset of the page in its stream's (conditioned) byte space
     const DcTable* dc;      // non-null for preconditioned streams
+    uint32_t index;         // global page index (position in stream order, before the schedule)
     bool     valid;
 };
 
@@ -777,9 +785,10 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
     PageJob job;
     job.valid = ok;
     job.in = nullptr; job.out = nullptr; job.in_size = job.out_size = 0; job.in_limit = 0; job.page_size = kMinPageSize;
-    job.page_off = 0; job.dc = nullptr;
+    job.page_off = 0; job.dc = nullptr; job.index = 0;
     if (job.valid) {
         if (order != nullptr) g = order[g];                             // the schedule built by the order kernels
+        job.index = g;
         const uint32_t* const page_base = a.page_base;
         const StreamDesc* const streams = a.streams;
         const uint8_t* const in = a.in;
@@ -934,7 +943,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
                                      L.limit[k], L.first_offs[k],
                                      k == 0u ? kIcpAlphabet : k == 1u ? kDistAlphabet : kLitAlphabet,
                                      k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit, far_syms};
-                    const bool ok = build_table(t, L, br, start, sl);
+                    const bool ok = build_table(t, L.win, br, start, sl);      // the window holds the code lengths meanwhile
                     tables_ok = tables_ok && ok;
                 }
                 if (start) {

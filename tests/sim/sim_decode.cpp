@@ -6,6 +6,7 @@
 #include <brotlig_wave_ops.h>
 
 #include "brotlig_kernels.h"
+#include "brotlig_split_kernels.h"
 
 using namespace brotlig;
 
@@ -49,6 +50,45 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     sim::run_grid(3, decond_body, &a);
     *status_out = status_words[0];
     g_last_policy = status_words[3];
+    return 0;
+}
+
+static void entropy_body(void* p) { brotlig_entropy_kernel(*(DecodeArgs*)p); }
+static void assemble_body(void* p) { brotlig_assemble_kernel(*(DecodeArgs*)p); }
+static int g_run_assemble = 0;
+static uint8_t* g_scratch = nullptr;
+extern "C" void sim_set_scratch(uint8_t* p) { g_scratch = p; }
+extern "C" void sim_set_assemble(int on) { g_run_assemble = on; }
+
+// Split path, first kernel only: the command / literal arrays of every page, for inspection by the tests.
+// cmds: [pages][cmd_cap + 1], lits: [pages][lit_stride], hdr: [pages][2]
+extern "C" int sim_entropy_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* out, uint64_t out_bytes,
+                                 const uint64_t* in_offsets, const uint64_t* out_offsets, uint32_t num_streams, uint32_t grid,
+                                 uint64_t* cmds, uint8_t* lits, uint32_t* hdr, uint32_t cmd_cap, uint32_t lit_stride, uint32_t* status_out)
+{
+    std::vector<StreamDesc> sd(num_streams);
+    for (uint32_t i = 0; i < num_streams; ++i) {
+        sd[i].in_offset = in_offsets[i]; sd[i].out_offset = out_offsets[i];
+        sd[i].in_size = (i + 1 < num_streams ? in_offsets[i + 1] : in_bytes) - in_offsets[i];
+        sd[i].out_capacity = (i + 1 < num_streams ? out_offsets[i + 1] : out_bytes) - out_offsets[i];
+    }
+    std::vector<uint32_t> page_base(num_streams + 1, 0);
+    uint32_t counter = 0, counter2 = 0;
+    uint32_t status_words[64] = {0};
+    std::vector<DcTable> dc(num_streams);
+    DecodeArgs a{};
+    a.in = in; a.in_bytes = in_bytes; a.out = out; a.out_bytes = out_bytes; a.scratch = g_scratch;
+    a.streams = sd.data(); a.num_streams = num_streams;
+    a.page_base = page_base.data(); a.work_counter = &counter; a.work_counter2 = &counter2; a.status = status_words; a.dc = dc.data();
+    const int decode_grid = grid ? grid : 4;
+    std::vector<uint16_t> far_syms((size_t)decode_grid * 2u * kFarSymStride, 0xFFFFu);
+    a.far_syms = far_syms.data();
+    a.cmds = cmds; a.lits = lits; a.slot_hdr = hdr; a.cmd_cap = cmd_cap; a.lit_stride = lit_stride;
+    sim::run_grid(1, prepare_body, &a);
+    sim::run_grid(1, policy_body, &a);
+    sim::run_grid(decode_grid, entropy_body, &a);
+    if (g_run_assemble) { sim::run_grid(decode_grid, assemble_body, &a); sim::run_grid(3, decond_body, &a); }
+    *status_out = status_words[0];
     return 0;
 }
 
