@@ -21,7 +21,11 @@
 #define BROTLIG_E_WAVES 5
 #endif
 #ifndef BROTLIG_L_WAVES
-#define BROTLIG_L_WAVES 6
+#define BROTLIG_L_WAVES 5
+#endif
+// assembly kernel, loads issued a step ahead: 0 none, 1 the command words, 2 also the literal bytes (staged through LDS)
+#ifndef BROTLIG_L_PREFETCH
+#define BROTLIG_L_PREFETCH 2
 #endif
 
 namespace brotlig {
@@ -335,8 +339,12 @@ struct __attribute__((aligned(16))) AssembleLds {      // one per 32-lane half
     uint32_t start_bits[kRoundMax / 32];
     uint8_t  start_cum[kRoundMax / 32];
     uint8_t  win[kWin + 16] __attribute__((aligned(16)));
+#if BROTLIG_L_PREFETCH >= 2
+    uint8_t  lit_stage[512 + 16] __attribute__((aligned(16)));     // the next 512 bytes of the literal array, fetched a step ahead
+#endif
 };
 struct __attribute__((aligned(16))) AssembleWaveLds { AssembleLds page[2]; };
+constexpr int kLPrefetch = BROTLIG_L_PREFETCH;
 
 // Pages from the second work counter; for each, the entropy kernel's slot: 32 commands per step and half-wave, positions
 // read from the command words, then the group loop of the fused kernel (brotlig_kernels.h, decode_pages, steps 3b-5b) with
@@ -357,6 +365,8 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
     uint32_t flushed = 0;
     const uint64_t* my_cmds = a.cmds;
     const uint8_t* my_lits = a.lits;
+    uint64_t pw0 = 0, pw1 = 0;       // the words of the step that starts at c0, loaded during the step before
+    uint32_t staged_base = 0xFFFFFFFFu;     // literal-array position of lit_stage[0] (none staged yet)
 
     for (;;) {
         // ---- page start: a free half takes the next page that has a ready slot (stored and rejected pages have none)
@@ -383,6 +393,8 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
                     my_cmds = a.cmds + (size_t)job.index * (a.cmd_cap + 1u);
                     my_lits = a.lits + (size_t)job.index * a.lit_stride;
                     live = true; need = false;
+                    staged_base = 0xFFFFFFFFu;
+                    if (kLPrefetch >= 1 && sl < min_u32(32u, n)) { pw0 = my_cmds[sl]; pw1 = my_cmds[sl + 1u]; }
                 }
             }
         }
@@ -394,13 +406,27 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
         const uint32_t n = live ? min_u32(32u, ncmd - c0) : 0u;
         const bool is_cmd = sl < n;
         uint64_t w0 = 0, w1 = 0;
-        if (is_cmd) { w0 = my_cmds[c0 + sl]; w1 = my_cmds[c0 + sl + 1u]; }
+        if (kLPrefetch >= 1) {
+            if (is_cmd) { w0 = pw0; w1 = pw1; }
+            const uint32_t cn = c0 + n;                                 // the next step's words: in flight during this one
+            if (live && cn + sl < ncmd) { pw0 = my_cmds[cn + sl]; pw1 = my_cmds[cn + sl + 1u]; }
+        } else if (is_cmd) { w0 = my_cmds[c0 + sl]; w1 = my_cmds[c0 + sl + 1u]; }
         const uint32_t cmd_out = (uint32_t)w0 & 0x3FFFFu, my_lit_pos = (uint32_t)(w0 >> 18) & 0x3FFFFu, dist = (uint32_t)(w0 >> 36) & 0x3FFFFu;
         const uint32_t next_out = (uint32_t)w1 & 0x3FFFFu, next_lit = (uint32_t)(w1 >> 18) & 0x3FFFFu;
         const uint32_t ins = next_lit - my_lit_pos, tot = next_out - cmd_out, copy = tot - ins;
         const uint32_t round_end = wave::half_bcast(next_out, n ? n - 1u : 0u);
         const uint32_t round_bytes = live ? round_end - out_pos : 0u;
         const uint32_t rel0 = cmd_out - out_pos;                        // my first byte, relative to the step
+        // the 512 bytes of the literal array behind this step's literals: requested now, stored to LDS at the step's end
+        uint64_t lp0 = 0, lp1 = 0;
+        uint32_t next_stage = 0xFFFFFFFFu;
+        if (kLPrefetch >= 2) {
+            const uint32_t nb = wave::half_bcast(next_lit, n ? n - 1u : 0u);        // first literal of the next step
+            if (live && c0 + n < ncmd && nb + 512u + 16u <= a.lit_stride) {
+                next_stage = nb;
+                lp0 = load_u64u(my_lits + nb + 16u * sl); lp1 = load_u64u(my_lits + nb + 16u * sl + 8u);
+            }
+        }
         const bool ok_cmd = is_cmd;
         const bool cp = ok_cmd && copy > 0u && dist != 0u;
         clk.lap(kPhPositions);
@@ -509,7 +535,19 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
             const uint8_t* const lsrc = my_lits + (my_lit_pos + (la - rel0));
             const uint32_t lclip = nlit >= 8u ? nlit - 8u : 0u;
             uint64_t le0 = 0, le1 = 0, le2 = 0, le3 = 0;
-            if (nlit != 0u && nlit <= kLitDirect) {
+            const uint32_t lfirst = my_lit_pos + (la - rel0);
+            bool staged_lit = false;                                    // my run lies in the part of the array staged in LDS
+#if BROTLIG_L_PREFETCH >= 2
+            staged_lit = nlit != 0u && nlit <= kLitDirect && lfirst >= staged_base && lfirst + nlit <= staged_base + 512u;
+            if (staged_lit) {
+                const uint8_t* q = L.lit_stage + (lfirst - staged_base);
+                le0 = load_u64u(q);
+                if (nlit > 8u) le1 = load_u64u(q + min_u32(8u, lclip));
+                if (nlit > 16u) le2 = load_u64u(q + min_u32(16u, lclip));
+                if (nlit > 24u) le3 = load_u64u(q + lclip);
+            }
+#endif
+            if (nlit != 0u && nlit <= kLitDirect && !staged_lit) {
                 le0 = load_u64u(lsrc);
                 if (nlit > 8u) le1 = load_u64u(lsrc + min_u32(8u, lclip));
                 if (nlit > 16u) le2 = load_u64u(lsrc + min_u32(16u, lclip));
@@ -771,6 +809,12 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
         }
 
 
+#if BROTLIG_L_PREFETCH >= 2
+        wave::sync();
+        if (next_stage != 0xFFFFFFFFu) { uint64_t v[2] = {lp0, lp1}; __builtin_memcpy(L.lit_stage + 16u * sl, v, 16); }
+        if (live) staged_base = next_stage;
+        wave::sync();
+#endif
         if (live) { out_pos += round_bytes; c0 += n; if (c0 >= ncmd) live = false; }
         } while (!wave::any(in_page && !live));
 
