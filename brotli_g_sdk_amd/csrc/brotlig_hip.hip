@@ -43,7 +43,8 @@ size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(D
 size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
 // Split path (brotlig_split_kernels.h; A/B experiment, switched on with BROTLIG_SPLIT=1): per page one slot of
 // (cap + 1) command words and a literal array of a page plus slack, and two header words.
-bool split_enabled() { static const bool on = [] { const char* e = getenv("BROTLIG_SPLIT"); return e && atoi(e) != 0; }(); return on; }
+int split_mode() { static const int m = [] { const char* e = getenv("BROTLIG_SPLIT"); return e ? atoi(e) : 0; }(); return m; }     // 1: LDS-window assembly, 2: in-place assembly
+bool split_enabled() { return split_mode() != 0; }
 uint32_t split_cmd_cap() { static const uint32_t c = [] { const char* e = getenv("BROTLIG_SPLIT_CAP"); return e ? (uint32_t)atoi(e) : 16384u; }(); return c; }
 constexpr uint32_t kLitStride = kMaxPageSize + 64u;
 size_t split_slot_bytes() { return ((size_t)split_cmd_cap() + 1u) * 8u + kLitStride + 8u; }
@@ -54,7 +55,7 @@ constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
 
 // Launch geometry per device (CU count x occupancy of the decode kernel), looked up once per device;
 // host threads driving different devices (or the same one) may arrive here concurrently.
-struct Grids { int decode = 0, decond = 1024, order = 1024, entropy = 0, assemble = 0; };
+struct Grids { int decode = 0, decond = 1024, order = 1024, entropy = 0, assemble = 0, assemble_global = 0; };
 constexpr int kMaxDevices = 64;
 std::mutex g_grid_mutex;
 Grids g_grids[kMaxDevices];
@@ -94,6 +95,7 @@ BROTLIG_ERROR grid_sizes(Grids* out)
         };
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_entropy_kernel), "BROTLIG_E_PER_CU", &g.entropy)) return e;
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_kernel), "BROTLIG_L_PER_CU", &g.assemble)) return e;
+        if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_global_kernel), "BROTLIG_G_PER_CU", &g.assemble_global)) return e;
     }
     *out = g;
     return BROTLIG_OK;
@@ -162,7 +164,8 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     if (k0) HIP_OK(hipEventRecord(k0, s));
     if (a.cmds != nullptr) {                                            // split path: entropy decode, then assembly
         hipLaunchKernelGGL(brotlig_entropy_kernel, dim3(g.entropy), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(brotlig_assemble_kernel, dim3(g.assemble), dim3(64), 0, s, a);
+        if (split_mode() == 2) hipLaunchKernelGGL(brotlig_assemble_global_kernel, dim3(g.assemble_global), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(brotlig_assemble_kernel, dim3(g.assemble), dim3(64), 0, s, a);
     } else {
         hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, s, a);
     }

@@ -866,6 +866,230 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
     }
 }
 
+
+// ---- assembly kernel, second form: the page is assembled IN PLACE in global memory --------------------------------------------
+// No LDS window: one wavefront per page, 64 commands per step; every command's lane copies its literal run from the literal
+// array and its LZ77 copy from `dist` bytes back straight into the output, in 8-byte chunks.  What makes that legal: a wave's
+// vector-memory requests are performed in order, so a load issued after a store of the same wave -- any lane -- sees it (the
+// fused kernel relies on the same for its far copies); copies that read what an earlier command of the same step writes run
+// in dependency levels, a copy that overlaps itself replays its pattern (the first `dist` bytes, complete before it starts)
+// instead of reading its own output.  The kernel keeps 260 bytes of LDS and a small register file: 32 waves per CU, and no
+// flush / slide / staging / piece bitmaps at all.  Recently written lines come back from the CU's L1 and the XCD's L2; far
+// sources cost what they cost the fused kernel.
+#ifndef BROTLIG_G_WAVES
+#define BROTLIG_G_WAVES 8
+#endif
+constexpr uint32_t kCoopLen = 64;          // pieces longer than this are copied by the whole wave, 8 bytes per lane and pass
+
+struct GlobalAsmLds { uint32_t pos[68]; };      // output position of each of the step's commands, then the step's end
+
+// `len` bytes from src to dst by the whole wave (all lanes call it with the same arguments); d = distance for a copy that may
+// overlap itself (d >= len: plain), or 0xFFFFFFFF for literals.  Source bytes are all in place before the call.
+__device__ __forceinline__ void coop_copy(uint8_t* dst, const uint8_t* src, uint32_t len, uint32_t d, uint32_t lane)
+{
+    for (uint32_t j = 8u * lane; j < len; j += 512u) {
+        uint64_t v;
+        if (d >= len) v = load_u64u(src + j);
+        else v = pattern_source8(src, d, mod_u16(j, d));
+        store_bytes(dst + j, v, len - j);
+    }
+}
+
+__device__ inline void assemble_pages_global(GlobalAsmLds& L, const DecodeArgs& a)
+{
+    const uint32_t lane = wave::lane_id();
+    const uint32_t total = a.page_base[a.num_streams];
+    const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
+    for (;;) {
+        uint32_t g = 0;
+        if (lane == 0u) g = atomicAdd(a.work_counter2, 1u);
+        g = wave::uniform(wave::bcast(g, 0u));
+        if (g >= total) break;
+        const PageJob job = fetch_job(a, order, g, true);
+        uint32_t ncmd = 0, flags = 0;
+        if (job.valid) { ncmd = a.slot_hdr[2u * job.index]; flags = a.slot_hdr[2u * job.index + 1u]; }
+        if ((flags & kSlotReady) == 0u || ncmd == 0u) continue;
+        const uint64_t* const cmds = a.cmds + (size_t)job.index * (a.cmd_cap + 1u);
+        const uint8_t* const lits = a.lits + (size_t)job.index * a.lit_stride;
+        uint8_t* const out = job.out;
+        uint64_t pw0 = 0, pw1 = 0;
+        if (lane < ncmd) { pw0 = cmds[lane]; pw1 = cmds[lane + 1u]; }
+
+        for (uint32_t c0 = 0; c0 < ncmd; c0 += 64u) {
+            const uint32_t n = min_u32(64u, ncmd - c0);
+            const bool is_cmd = lane < n;
+            const uint64_t w0 = pw0, w1 = pw1;
+            if (c0 + 64u + lane < ncmd) { pw0 = cmds[c0 + 64u + lane]; pw1 = cmds[c0 + 65u + lane]; }     // next step's, in flight meanwhile
+            const uint32_t cmd_out = (uint32_t)w0 & 0x3FFFFu, lit_pos = (uint32_t)(w0 >> 18) & 0x3FFFFu, dist = (uint32_t)(w0 >> 36) & 0x3FFFFu;
+            const uint32_t next_out = (uint32_t)w1 & 0x3FFFFu, next_lit = (uint32_t)(w1 >> 18) & 0x3FFFFu;
+            const uint32_t ins = is_cmd ? next_lit - lit_pos : 0u;
+            const uint32_t copy = (is_cmd && dist != 0u) ? (next_out - cmd_out) - ins : 0u;
+            const uint32_t cdst = cmd_out + ins, src = cdst - dist;
+            const uint32_t pattern = min_u32(copy, dist), src_end = src + pattern;
+            const uint32_t S0 = wave::uniform(wave::bcast(cmd_out, 0u));          // first byte of the step
+            // positions of the step's commands, for the dependency search below
+            wave::sync();
+            if (is_cmd) L.pos[lane] = cmd_out;
+            if (lane == n - 1u) L.pos[n] = next_out;
+            wave::sync();
+
+            // -- copies whose source lies below the step (nearly all far ones, most near ones): loads first, they take longest
+            const bool has_copy = copy != 0u;
+            const bool simple = dist >= copy;                                     // no overlap with itself
+            const bool own = has_copy && copy <= kCoopLen;                         // copied by its own lane
+            const bool early = own && simple && src_end <= S0;
+            const uint32_t cclip = copy >= 8u ? copy - 8u : 0u;
+            uint64_t e0 = 0, e1 = 0;
+            if (early) {
+                e0 = load_u64u(out + src);
+                if (copy > 8u) e1 = load_u64u(out + src + min_u32(8u, cclip));
+            }
+            // -- literal runs (PageDecoder.cpp:209-211): short ones by their own lane, long ones by the whole wave
+            {
+                const uint32_t lclip = ins >= 8u ? ins - 8u : 0u;
+                const bool lown = ins != 0u && ins <= kCoopLen;
+                uint64_t l0 = 0, l1 = 0;
+                if (lown) {
+                    l0 = load_u64u(lits + lit_pos);
+                    if (ins > 8u) l1 = load_u64u(lits + lit_pos + min_u32(8u, lclip));
+                }
+                if (lown) {
+                    if (ins >= 8u) {
+                        __builtin_memcpy(out + cmd_out, &l0, 8);
+                        if (ins > 8u) __builtin_memcpy(out + cmd_out + min_u32(8u, lclip), &l1, 8);
+                    } else store_bytes(out + cmd_out, l0, ins);
+                }
+                for (uint32_t o = 16u; wave::any(lown && ins > o); o += 16u) {       // runs of 17..64 bytes: further chunk pairs
+                    if (lown && ins > o) {
+                        const uint32_t c0o = min_u32(o, lclip), c1o = min_u32(o + 8u, lclip);
+                        const uint64_t v0 = load_u64u(lits + lit_pos + c0o), v1 = load_u64u(lits + lit_pos + c1o);
+                        __builtin_memcpy(out + cmd_out + c0o, &v0, 8);
+                        __builtin_memcpy(out + cmd_out + c1o, &v1, 8);
+                    }
+                }
+                uint64_t lmask = wave::ballot64(ins > kCoopLen);
+                while (lmask != 0ull) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(lmask);
+                    lmask &= lmask - 1ull;
+                    const uint32_t k_dst = wave::uniform(wave::bcast(cmd_out, k)), k_src = wave::uniform(wave::bcast(lit_pos, k));
+                    const uint32_t k_len = wave::uniform(wave::bcast(ins, k));
+                    coop_copy(out + k_dst, lits + k_src, k_len, 0xFFFFFFFFu, lane);
+                }
+            }
+            // early copies: their bytes are here by now
+            if (early) {
+                if (copy >= 8u) {
+                    __builtin_memcpy(out + cdst, &e0, 8);
+                    if (copy > 8u) __builtin_memcpy(out + cdst + min_u32(8u, cclip), &e1, 8);
+                } else store_bytes(out + cdst, e0, copy);
+            }
+            for (uint32_t o = 16u; wave::any(early && copy > o); o += 16u) {
+                if (early && copy > o) {
+                    const uint32_t c0o = min_u32(o, cclip), c1o = min_u32(o + 8u, cclip);
+                    const uint64_t v0 = load_u64u(out + src + c0o), v1 = load_u64u(out + src + c1o);
+                    __builtin_memcpy(out + cdst + c0o, &v0, 8);
+                    __builtin_memcpy(out + cdst + c1o, &v1, 8);
+                }
+            }
+
+            // -- the rest in dependency levels.  A copy waits for the commands of this step (before it) whose COPY bytes its
+            //    source touches; their literals are in place already.  [lo_l, hi_l) = those commands: binary search in pos[].
+            uint32_t lo_l = 0, hi_l = 0;
+            const bool late = has_copy && !early;
+            if (wave::any(late && src_end > S0)) {
+                // largest l with pos[l] <= x, for x = max(src, S0) and x = src_end - 1 (both >= S0 = pos[0])
+                const uint32_t xa = src > S0 ? src : S0, xb = src_end - 1u;
+                uint32_t la = 0, lb = 0;
+                for (uint32_t step = 32u; step != 0u; step >>= 1) {
+                    const uint32_t ta = la + step, tb = lb + step;
+                    const uint32_t pa = L.pos[min_u32(ta, n)], pb = L.pos[min_u32(tb, n)];
+                    if (ta < n && pa <= xa) la = ta;
+                    if (tb < n && pb <= xb) lb = tb;
+                }
+                if (late && src_end > S0) { lo_l = la; hi_l = min_u32(lb + 1u, lane); }
+            }
+            uint64_t todo = wave::ballot64(late);
+            while (todo != 0ull) {
+                const uint64_t window = hi_l > lo_l ? ((todo >> lo_l) & ((hi_l - lo_l) >= 64u ? ~0ull : ((1ull << (hi_l - lo_l)) - 1ull))) : 0ull;
+                const bool ready = late && ((todo >> lane) & 1ull) != 0ull && window == 0ull;
+                // own-lane pieces: plain ones in chunk pairs at clipped offsets, self-overlapping ones from their pattern
+                const bool r_own = ready && own;
+                if (r_own && simple) {
+                    uint64_t v0 = load_u64u(out + src), v1 = 0;
+                    if (copy > 8u) v1 = load_u64u(out + src + min_u32(8u, cclip));
+                    if (copy >= 8u) {
+                        __builtin_memcpy(out + cdst, &v0, 8);
+                        if (copy > 8u) __builtin_memcpy(out + cdst + min_u32(8u, cclip), &v1, 8);
+                    } else store_bytes(out + cdst, v0, copy);
+                }
+                for (uint32_t o = 16u; wave::any(r_own && simple && copy > o); o += 16u) {
+                    if (r_own && simple && copy > o) {
+                        const uint32_t c0o = min_u32(o, cclip), c1o = min_u32(o + 8u, cclip);
+                        const uint64_t v0 = load_u64u(out + src + c0o), v1 = load_u64u(out + src + c1o);
+                        __builtin_memcpy(out + cdst + c0o, &v0, 8);
+                        __builtin_memcpy(out + cdst + c1o, &v1, 8);
+                    }
+                }
+                for (uint32_t o = 0u; wave::any(r_own && !simple && o < copy); o += 8u) {
+                    if (r_own && !simple && o < copy) store_bytes(out + cdst + o, pattern_source8(out + src, dist, mod_u16(o, dist)), copy - o);
+                }
+                // long pieces that are ready: the whole wave, one piece after the other
+                uint64_t big = wave::ballot64(ready && !own);
+                while (big != 0ull) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(big);
+                    big &= big - 1ull;
+                    const uint32_t k_dst = wave::uniform(wave::bcast(cdst, k)), k_src = wave::uniform(wave::bcast(src, k));
+                    const uint32_t k_len = wave::uniform(wave::bcast(copy, k)), k_d = wave::uniform(wave::bcast(dist, k));
+                    coop_copy(out + k_dst, out + k_src, k_len, k_d, lane);
+                }
+                todo &= ~wave::ballot64(ready);
+            }
+        }
+
+        // per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): lanes 0..31, as in the fused kernel
+        if ((flags & kSlotDelta) != 0u) {
+            wave::global_fence();
+            const uint32_t sl = lane & 31u;
+            const bool lower = lane < 32u;
+            for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
+                uint32_t lo = 0, hi = 0;
+                if ((job.dc->color_mask >> c) & 1u) {
+                    const uint32_t cs = job.dc->sub_stream_off[c], ce = job.dc->sub_stream_off[c + 1];
+                    const uint32_t ps = job.page_off, pe = job.page_off + job.out_size;
+                    if (cs < pe && ps < ce) { lo = (cs > ps ? cs : ps) - ps; hi = (ce < pe ? ce : pe) - ps; }
+                }
+                uint32_t carry = 0;
+                for (uint32_t base = lo & ~15u; base < hi; base += 512u) {
+                    const uint32_t pos = base + sl * 16u;
+                    const bool full = lower && pos >= lo && pos + 16u <= hi;
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+                    if (full) {
+                        __builtin_memcpy(w, __builtin_assume_aligned(out + pos, 16), 16);
+                    } else if (lower) {
+                        for (uint32_t i = 0; i < 16u; ++i)
+                            if (pos + i >= lo && pos + i < hi) w[i >> 2] |= (uint32_t)out[pos + i] << (8u * (i & 3u));
+                    }
+                    w[0] = byte_prefix(w[0]);
+                    w[1] = byte_add(byte_prefix(w[1]), w[0] >> 24);
+                    w[2] = byte_add(byte_prefix(w[2]), w[1] >> 24);
+                    w[3] = byte_add(byte_prefix(w[3]), w[2] >> 24);
+                    const uint32_t tot = w[3] >> 24;
+                    const uint32_t incl = wave::half_scan_incl(tot) & 0xFFu;
+                    const uint32_t add = (carry + incl - tot) & 0xFFu;
+                    for (uint32_t k = 0; k < 4u; ++k) w[k] = byte_add(w[k], add);
+                    if (full) {
+                        __builtin_memcpy(__builtin_assume_aligned(out + pos, 16), w, 16);
+                    } else if (lower) {
+                        for (uint32_t i = 0; i < 16u; ++i)
+                            if (pos + i >= lo && pos + i < hi) out[pos + i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
+                    }
+                    carry = (carry + wave::half_shfl(incl, 31u)) & 0xFFu;
+                }
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(64, BROTLIG_E_WAVES) brotlig_entropy_kernel(DecodeArgs a)
 {
     __shared__ EntropyWaveLds W;
@@ -879,6 +1103,12 @@ __global__ void __launch_bounds__(64, BROTLIG_L_WAVES) brotlig_assemble_kernel(D
 {
     __shared__ AssembleWaveLds W;
     assemble_pages(W, a);
+}
+
+__global__ void __launch_bounds__(64, BROTLIG_G_WAVES) brotlig_assemble_global_kernel(DecodeArgs a)
+{
+    __shared__ GlobalAsmLds L;
+    assemble_pages_global(L, a);
 }
 
 }  // namespace brotlig

@@ -110,7 +110,7 @@ def test_entropy_kernel_batch_of_streams(sim):
 
 
 # ---- both kernels: entropy -> assembly (-> de-conditioning), against the encoder's input / the oracle -------------------------
-def run_split(sim, streams, sizes, precon=False):
+def run_split(sim, streams, sizes, precon=False, mode=1):
     buf, in_bytes, io, oo, opos = layout(streams, sizes)
     out = np.full(opos + 64, 0xCD, np.uint8)
     scratch = np.full(opos + 64, 0xEE, np.uint8)
@@ -122,7 +122,7 @@ def run_split(sim, streams, sizes, precon=False):
     st = ctypes.c_uint32(0)
     sim.sim_set_scratch.argtypes = [ctypes.c_void_p]
     sim.sim_set_scratch(scratch.ctypes.data if precon else None)
-    sim.sim_set_assemble(1)
+    sim.sim_set_assemble(mode)
     try:
         sim.sim_entropy_batch(buf.ctypes.data, in_bytes, out.ctypes.data, opos, io.ctypes.data, oo.ctypes.data, len(streams), 3,
                               cmds.ctypes.data, lits.ctypes.data, hdr.ctypes.data, CMD_CAP, LIT_STRIDE, ctypes.byref(st))
@@ -162,4 +162,34 @@ def test_split_path_batch_and_random_streams(sim):
     for seed in range(60):
         data, kw = random_plain(seed)
         outs, status = run_split(sim, [E.encode(data, **kw)], [len(data)])
+        assert status == 0 and np.array_equal(outs[0], data), seed
+
+
+# ---- the same with the in-place assembly kernel (no LDS window; one wavefront per page) -------------------------------------------
+@pytest.mark.parametrize("name,thunk,kw", plain_cases() + raw_stress_cases() + symbol_overflow_cases(), ids=lambda v: v if isinstance(v, str) else "")
+def test_split_path_global_assembly_plain(sim, name, thunk, kw):
+    data = np.ascontiguousarray(thunk(), dtype=np.uint8)
+    outs, status = run_split(sim, [E.encode(data, **kw)], [len(data)], mode=2)
+    assert status == 0 and np.array_equal(outs[0], data)
+
+
+def test_split_path_global_assembly_preconditioned_batch_random(sim):
+    from cases import precon_cases
+    from fuzzcases import random_plain
+    from helpers import oracle_decode
+    for name, thunk, pre in precon_cases():
+        tex = thunk()
+        stream = E.encode(tex, precondition=pre)
+        rc, ref = oracle_decode(stream, out_size=len(tex))
+        assert rc == 0
+        outs, status = run_split(sim, [stream], [len(tex)], precon=True, mode=2)
+        assert status == 0 and np.array_equal(outs[0], ref), name
+    datas = [D.text(65536 + 100, 1), D.runs(3 * 65536, 2), D.random_bytes(65536, 3), D.records(2 * 65536 + 1, 4), D.mixed(65536, 5)]
+    outs, status = run_split(sim, [E.encode(d) for d in datas], [len(d) for d in datas], mode=2)
+    assert status == 0
+    for o, d in zip(outs, datas):
+        assert np.array_equal(o, d)
+    for seed in range(80):
+        data, kw = random_plain(seed)
+        outs, status = run_split(sim, [E.encode(data, **kw)], [len(data)], mode=2)
         assert status == 0 and np.array_equal(outs[0], data), seed
