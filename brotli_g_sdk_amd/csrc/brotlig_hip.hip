@@ -19,7 +19,9 @@
 
 #include "brotlig_amd.h"
 #include "brotlig_kernels.h"
+#ifdef BROTLIG_WITH_SPLIT     // experiment builds only (profiles/experiments/r03_split_path.md): not part of the product library
 #include "brotlig_split_kernels.h"
+#endif
 
 using namespace brotlig;
 
@@ -41,13 +43,19 @@ constexpr uint32_t kMaxDecodeGrid = 8192;
 constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
 size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
 size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
-// Split path (brotlig_split_kernels.h; A/B experiment, switched on with BROTLIG_SPLIT=1): per page one slot of
-// (cap + 1) command words and a literal array of a page plus slack, and two header words.
+// Split path (brotlig_split_kernels.h): an A/B experiment of round 3, compiled in with -DBROTLIG_WITH_SPLIT only and then
+// switched on with BROTLIG_SPLIT=1|2.  Per page one slot of (cap + 1) command words and a literal array of a page plus
+// slack, and two header words.
+#ifdef BROTLIG_WITH_SPLIT
 int split_mode() { static const int m = [] { const char* e = getenv("BROTLIG_SPLIT"); return e ? atoi(e) : 0; }(); return m; }     // 1: LDS-window assembly, 2: in-place assembly
 bool split_enabled() { return split_mode() != 0; }
 uint32_t split_cmd_cap() { static const uint32_t c = [] { const char* e = getenv("BROTLIG_SPLIT_CAP"); return e ? (uint32_t)atoi(e) : 16384u; }(); return c; }
 constexpr uint32_t kLitStride = kMaxPageSize + 64u;
 size_t split_slot_bytes() { return ((size_t)split_cmd_cap() + 1u) * 8u + kLitStride + 8u; }
+#else
+bool split_enabled() { return false; }
+size_t split_slot_bytes() { return 0; }
+#endif
 // every page is at least 32 KiB of output, and every stream's output region is whole pages
 uint64_t max_pages(uint32_t n, uint64_t out_bytes) { return out_bytes / kMinPageSize + n; }
 // Below this many pages the schedule is not worth its two extra launches (about two pages per half-wave).
@@ -93,9 +101,13 @@ BROTLIG_ERROR grid_sizes(Grids* out)
             *out = cus * n < (int)kMaxDecodeGrid ? cus * n : (int)kMaxDecodeGrid;
             return BROTLIG_OK;
         };
+#ifdef BROTLIG_WITH_SPLIT
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_entropy_kernel), "BROTLIG_E_PER_CU", &g.entropy)) return e;
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_kernel), "BROTLIG_L_PER_CU", &g.assemble)) return e;
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_global_kernel), "BROTLIG_G_PER_CU", &g.assemble_global)) return e;
+#else
+        (void)grid_of;
+#endif
     }
     *out = g;
     return BROTLIG_OK;
@@ -133,6 +145,7 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
         used = base + 4u * max_pages(n, out_bytes);
     }
     a.work_counter2 = ws + 4;
+#ifdef BROTLIG_WITH_SPLIT
     if (split_enabled()) {                                              // slots behind the schedule, if the workspace has them
         const uint64_t pages = max_pages(n, out_bytes);
         used = (used + 255u) & ~(size_t)255u;
@@ -144,6 +157,7 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
             a.slot_hdr = reinterpret_cast<uint32_t*>(p);
         }
     }
+#endif
     return a;
 }
 
@@ -162,13 +176,14 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     if (const char* e = getenv("BROTLIG_POLICY"))       // diagnostics: pin the pairing policy (quarters of a page a free half waits)
         HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), atoi(e), 1, s));
     if (k0) HIP_OK(hipEventRecord(k0, s));
+#ifdef BROTLIG_WITH_SPLIT
     if (a.cmds != nullptr) {                                            // split path: entropy decode, then assembly
         hipLaunchKernelGGL(brotlig_entropy_kernel, dim3(g.entropy), dim3(64), 0, s, a);
         if (split_mode() == 2) hipLaunchKernelGGL(brotlig_assemble_global_kernel, dim3(g.assemble_global), dim3(64), 0, s, a);
         else hipLaunchKernelGGL(brotlig_assemble_kernel, dim3(g.assemble), dim3(64), 0, s, a);
-    } else {
-        hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, s, a);
-    }
+    } else
+#endif
+    hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, s, a);
     if (k1) HIP_OK(hipEventRecord(k1, s));
     {   // streams over y, each stream's tiles over x; about 8 workgroups of 256 per CU in total
         const unsigned gy = a.num_streams < 32u ? a.num_streams : 32u;

@@ -11,12 +11,12 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cs=$root/brotli_g_sdk_amd/csrc
 build() { # name E L
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I "$root/include" -I "$cs" -DBROTLIG_E_WAVES=$2 -DBROTLIG_L_WAVES=$3 \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/include" -I "$cs" -DBROTLIG_E_WAVES=$2 -DBROTLIG_L_WAVES=$3 \
         -o "$out/lib_$1.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"
 }
 build e5l5 5 5; build e5l6 5 6; build e5l8 5 8; build e4l6 4 6
 # parity on the split path (default build = e5l6): the C-ABI tests with the split path switched on
-( export BROTLIG_SPLIT=1; python -m pytest tests/test_gpu_decode.py tests/test_gpu_differential.py -m gpu -x -q ) > "$out/pytest_split.log" 2>&1
+( export BROTLIG_SPLIT=1 BROTLIG_HIP_SO="$out/lib_e5l6.so"; python -m pytest tests/test_gpu_decode.py tests/test_gpu_differential.py -m gpu -x -q ) > "$out/pytest_split.log" 2>&1
 tail -3 "$out/pytest_split.log"
 for w in mixed text records runs; do
   s=16; [ $w = runs ] && s=16
