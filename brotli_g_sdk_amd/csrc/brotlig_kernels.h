@@ -854,7 +854,15 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
     // ---- per-half state of the page under construction
     PageJob job = fetch_job(a, nullptr, 0u, false);
     bool live = false;               // inside a compressed page
-    bool finished = false;           // the work counter ran out for this half
+    // Small batches: with fewer pages than half-waves a page decodes fastest ALONE in its wavefront (no lock-step with a
+    // neighbour: every phase of a round costs the maximum over the two halves).  So the upper halves only take part in as many
+    // wavefronts as there are pages beyond one per wavefront; from two pages per wavefront on, every half works.
+    bool finished = false;           // the work counter ran out for this half (or it sits this launch out)
+    {
+        const uint32_t total0 = a.page_base[a.num_streams];
+        const uint32_t doubles = total0 > gridDim.x ? total0 - gridDim.x : 0u;     // wavefronts that need both halves
+        if (lane >= 32u && blockIdx.x >= doubles) finished = true;
+    }
     BitReader br;
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
     uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16;             // PageDecoder.cpp:150-153

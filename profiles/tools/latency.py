@@ -15,4 +15,19 @@ for kind in ("runs", "mixed"):
         tot, k = dec.timed(3, 20)
         assert np.array_equal(dec.output(0)[:len(base)], base)
         out[f"{kind}_{pages}"] = {"kernel_ms": round(k, 4), "GBps": round(pages * 65536 / k / 1e6, 1)}
+# single assets through the host-pointer entry: DecodeGPU (a context per call: allocations) against a reusable BrotligContext
+import time
+ctx = api.Context()
+for name, n in (("asset_64KiB", 65536), ("asset_1MiB", 1 << 20), ("asset_16MiB", 16 << 20)):
+    data = D.mixed(n, 5)
+    s = E.encode(data)
+    for label, fn in (("DecodeGPU", api.DecodeGPU), ("BrotligContextDecodeGPU", ctx.DecodeGPU)):
+        o, k = fn(s)
+        assert np.array_equal(o, data)
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < 0.5:
+            o, k = fn(s); reps += 1
+        wall = (time.perf_counter() - t0) / reps * 1e3
+        out[f"{name}_{label}"] = {"wall_ms_host_to_host": round(wall, 3), "kernel_ms": round(k, 4), "GBps_host_to_host": round(n / wall / 1e6, 2)}
+ctx.close()
 print(json.dumps(out))

@@ -9,7 +9,7 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 pre = os.path.join(dst, f"r{rnd}_{tag}_")
 
-for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16", "bench_records", "bench_distinct4096", "latency"):
+for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16", "bench_records", "bench_distinct4096", "latency", "streamer_bench", "cpu_decode"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, pre + name + ".json")
@@ -51,12 +51,21 @@ j = {
     "fetch_bytes_per_launch": fetch * 1024, "write_bytes_per_launch": write * 1024,
     "traffic_bytes_per_launch_raw": (fetch + write) * 1024,
     "traffic_bytes_per_launch_fetch_doubled": (2 * fetch + write) * 1024,
+    "traffic_bytes_per_launch_calibrated": (2 * fetch + write) * 1024,
     "algorithmic_bytes_per_launch": alg,
     "note": "two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) with --kernel-trace only. "
-            "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads exactly half of a wide coalesced streaming read; "
-            "narrow/scattered reads (this kernel: 8-byte loads) and WRITE_SIZE are uncalibrated, so both the raw "
-            "and the read-doubled sums are given.",
+            "Calibrated in round 3 on known byte counts in this kernel's own access patterns (profiles/r03_traffic_calibration.md, "
+            "profiles/tools/traffic_calib.hip): every read request beyond L2 is a 128-byte line that FETCH_SIZE tallies as 64 bytes "
+            "(8-byte per-lane loads as well as wide ones), WRITE_SIZE counts 64-byte requests correctly: "
+            "traffic = 2 x FETCH_SIZE + WRITE_SIZE.",
 }
+try:                    # the requests behind the two derived counters, and the L2 hit rate (one more pass)
+    rd, _ = pmc("pmc_tcc", "TCC_EA0_RDREQ_sum"); wr, _ = pmc("pmc_tcc", "TCC_EA0_WRREQ_sum")
+    hit, _ = pmc("pmc_tcc", "TCC_HIT_sum"); miss, _ = pmc("pmc_tcc", "TCC_MISS_sum")
+    j["tcc"] = {"TCC_EA0_RDREQ_sum": rd, "TCC_EA0_WRREQ_sum": wr, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
+                "read_bytes_beyond_l2": rd * 128, "write_bytes_beyond_l2": wr * 64, "l2_hit_rate": hit / (hit + miss) if hit + miss else None}
+except Exception as e:
+    j["tcc"] = {"error": str(e)[:80]}
 json.dump(j, open(pre + "hbm_traffic.json", "w"), indent=1)
 # SQ counters (two passes), decode kernel only, averaged over its dispatches
 sq = {}

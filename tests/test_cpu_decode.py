@@ -43,8 +43,11 @@ def test_gpu_host_code_never_touches_the_cpu_library():
     for f in ("api.py", "shard.py", os.path.join("csrc", "brotlig_hip.hip"), os.path.join("csrc", "brotlig_streamer.hip")):
         text = open(os.path.join(ROOT, "brotli_g_sdk_amd", f)).read()
         assert "brotlig_cpu" not in text and "DecodeCPU(" not in text.replace("DecodeCPU / DecodeGPU", ""), f
+    # bench.py may time DecodeCPU, but only inside its cpu_baseline leg (a reported figure next to the oracle's)
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    assert "brotlig_cpu" not in bench and "import cpu" not in bench
+    a, b = bench.index("def cpu_baseline("), bench.index("def kernel_source_hash(")
+    outside = bench[:a] + bench[b:]
+    assert "brotlig_cpu" not in outside and "import cpu" not in outside and "product_cpu" not in outside
 
 
 @pytest.mark.parametrize("name,thunk,kw", plain_cases() + raw_stress_cases()[:4] + symbol_overflow_cases(), ids=lambda v: v if isinstance(v, str) else "")
