@@ -828,6 +828,233 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
     return job;
 }
 
+// ===========================================================================================
+// Stages of a page decode shared by the fused kernel (decode_pages) and the entropy kernel of the
+// split experiment (brotlig_split_kernels.h).  `Lds` is the per-half LDS record: both kinds carry
+// lut_icp / lut_dist / lut_lit, sorted_*, limit, first_offs, page_params and ring_push under
+// these names; where a table's code lengths live while it is built differs (build_lens).
+// All of them run in wave-uniform control flow, with per-half predicates as operands.
+
+template <class Lds>
+__device__ __forceinline__ TableRef table_of(Lds& L, uint32_t k, uint16_t* far_syms)
+{
+    return TableRef{k == 0u ? L.lut_icp : k == 1u ? L.lut_dist : L.lut_lit,
+                    k == 0u ? L.sorted_icp : k == 1u ? L.sorted_dist : L.sorted_lit,
+                    L.limit[k], L.first_offs[k],
+                    k == 0u ? kIcpAlphabet : k == 1u ? kDistAlphabet : kLitAlphabet,
+                    k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit, far_syms};
+}
+// fused kernel: the output window holds the code lengths of whichever table is being built
+__device__ __forceinline__ uint8_t* build_lens(PageLds& L, uint32_t) { return L.win; }
+
+// ---- stage: page start.  The halves with `want` take pages from the work counter until each holds a compressed one
+// (stored pages, PageDecoder.cpp:70-76, are copied on the spot; rejected ones skipped), then read the page header and
+// the sub-stream size table (:79-121), start their bit readers and build the three prefix-code tables (:125-147).
+// `on_pull(job)` is called by every lane of a half for every page the half takes.  Returns whether this half starts a
+// page; `tables_ok` = all three descriptions were defined.
+template <class Lds, class OnPull, class Clock>
+__device__ __forceinline__ bool start_pages(const DecodeArgs& a, Lds& L, PageJob& job, BitReader& br, bool want, bool& finished,
+                                            uint32_t sl, uint16_t* far_syms, bool& tables_ok, OnPull on_pull, Clock& clk)
+{
+    const uint32_t total = a.page_base[a.num_streams];
+    const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
+    uint32_t* const work_counter = a.work_counter;
+    bool need = want, start = false;
+    while (wave::any(need)) {
+        uint32_t g = 0;
+        if (need && sl == 0u) g = atomicAdd(work_counter, 1u);
+        g = wave::half_bcast(g, 0u);
+        const bool got = need && g < total;
+        if (need && !got) { finished = true; need = false; }
+        {
+            const PageJob nj = fetch_job(a, order, g, got);
+            if (got) job = nj;
+        }
+        if (got) on_pull(job);
+        const bool fresh = got && job.valid;
+        const bool stored = fresh && job.in_size == job.out_size;
+        if (stored) {                                       // plain copy, 4 bytes per lane per step
+            const uint32_t words = job.out_size >> 2;
+            for (uint32_t i = sl; i < words; i += 32u)
+                reinterpret_cast<uint32_t*>(job.out)[i] = load_u32(job.in + 4u * i);
+            for (uint32_t i = (words << 2) + sl; i < job.out_size; i += 32u) job.out[i] = job.in[i];
+        }
+        if (fresh && !stored) { start = true; need = false; }
+    }
+    {
+        uint32_t my_len = 0, hdr_bytes = 0;
+        if (start) {
+            const uint32_t w0 = br_load(job, 0u), w1 = br_load(job, 4u);
+            const uint64_t h = (uint64_t)w0 | ((uint64_t)w1 << 32);
+            const uint32_t npostfix = (uint32_t)h & 3u;
+            const uint32_t is_delta = ((((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr) ? 1u : 0u;   // PageDecoder.cpp:87-88
+            // kept in LDS rather than in a register for the whole page: read once per round at most
+            if (sl == 0u) L.page_params = npostfix | ((((uint32_t)h >> 2) & 15u) << (npostfix + 8u)) | (is_delta << 16);
+            const uint32_t base_bits = bit_width_u32((job.in_size + 31u) / 32u);
+            const uint32_t dsize_bits = bit_width_u32(bit_width_u32(job.in_size - 1u));
+            const uint32_t base_size = (uint32_t)(h >> 8) & ((1u << base_bits) - 1u);
+            const uint32_t delta_bits = (uint32_t)(h >> (8u + base_bits)) & ((1u << dsize_bits) - 1u);
+            const uint32_t table_at = 8u + base_bits + dsize_bits;
+            const uint32_t bit = table_at + sl * delta_bits;
+            const uint32_t wi = (bit >> 5) * 4u;
+            const uint64_t d = (uint64_t)br_load(job, wi) | ((uint64_t)br_load(job, wi + 4u) << 32);
+            const uint32_t delta = (uint32_t)(d >> (bit & 31u)) & ((1u << delta_bits) - 1u);
+            my_len = base_size + delta;
+            hdr_bytes = ((table_at + 32u * delta_bits + 31u) / 32u) * 4u;
+        }
+        const uint32_t incl = wave::half_scan_incl(my_len);
+        if (start) br.init(job.in, job.in_limit, hdr_bytes + incl - my_len);
+    }
+    clk.lap(kPhSetup);
+    // one copy of the table builder in the instruction stream, run three times (ICP, distance, literal):
+    // inlined three times it was most of the kernel's code size, beyond what the instruction cache holds
+    tables_ok = true;
+#pragma nounroll
+    for (uint32_t k = 0; k < 3u; ++k) {
+        const bool ok = build_table(table_of(L, k, far_syms), build_lens(L, k), br, start, sl);
+        tables_ok = tables_ok && ok;
+    }
+    return start;
+}
+
+// ---- stage: the commands of a round (PageDecoder.cpp:290-320, :338-404; format A.6 step 1, A.7, A.8).
+struct RoundCommands {
+    uint32_t sent_mask;     // lanes of the half that decoded the sentinel (704): the page's last round
+    uint32_t n;             // real commands of the round (0..32)
+    bool     is_cmd;        // this lane holds one
+    uint32_t ins, copy;     // insert and copy length (copy 0: insert-only command)
+    uint32_t dcode;         // distance code (0 = implicit "last distance")
+    uint32_t dist;          // distance for explicit codes >= 16; ring codes are resolved by resolve_distance_ring
+};
+// One command per lane.  Two refill points per command: with >= 32 bits in the window the command symbol (<= 15 bits)
+// leaves >= 17 for the insert/copy extra bits, and likewise the distance symbol for its extra bits; longer fields
+// (rare) take the general read.
+template <class Lds, class Clock>
+__device__ __forceinline__ RoundCommands decode_round_commands(const Lds& L, const uint32_t* len_code_tab, const TableRef& t_icp, const TableRef& t_dist,
+                                                                BitReader& br, bool live, uint32_t sl, Clock& clk)
+{
+    RoundCommands c;
+    uint32_t sym = 0, len = 0;
+    if (live) { br.ensure(32); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
+    clk.lap(kPhCmdSym);
+    c.sent_mask = wave::half_ballot(live && sym == kSentinel);
+    c.n = c.sent_mask ? ctz_u32(c.sent_mask) : 32u;
+    c.is_cmd = live && sl < c.n;
+    if (live && sl <= c.n) br.consume(len);                           // the sentinel's own bits are consumed too
+    c.ins = 0; c.copy = 0; c.dist = 0; c.dcode = 0;
+    if (c.is_cmd) {
+        // insert and copy length codes (for insert-only symbols 705..727 the copy length stays 0)
+        const bool has_copy = sym < kSentinel;
+        const uint32_t cell = sym >> 6;
+        const uint32_t ic = has_copy ? ((0x298500u >> (2u * cell)) & 3u) * 8u + ((sym >> 3) & 7u) : min_u32(sym - kSentinel, 23u);
+        const uint32_t cc = ((0x262444u >> (2u * cell)) & 3u) * 8u + (sym & 7u);
+        const uint32_t it = len_code_tab[ic], ct = has_copy ? len_code_tab[24u + cc] : 0u;
+        const uint32_t ie = it >> 16, ce = ct >> 16;
+        uint32_t xi, xc;
+        if (ie + ce <= 17u) {                                       // both fields are already in the window
+            const uint32_t x = br.peek(ie + ce);
+            br.consume(ie + ce);
+            xi = x & ((1u << ie) - 1u); xc = x >> ie;
+        } else { xi = br.read(ie); xc = br.read(ce); }
+        c.ins = (it & 0xFFFFu) + xi;
+        c.copy = has_copy ? (ct & 0xFFFFu) + xc : 0u;
+        clk.lap(kPhCmdExtra);
+        if (has_copy && sym >= 128u) {                              // explicit distance symbol
+            uint32_t dl;
+            br.ensure(32);
+            c.dcode = decode_symbol<kLutBitsDist>(t_dist, br, dl);
+            br.consume(dl);
+            if (c.dcode >= 16u) {                                   // PageDecoder.cpp:365-390
+                const uint32_t pp = L.page_params;
+                const uint32_t npostfix = pp & 3u, ndirect = (pp >> 8) & 0xFFu;
+                if (c.dcode < 16u + ndirect) c.dist = c.dcode - 15u;
+                else {
+                    const uint32_t x = c.dcode - ndirect - 16u;
+                    const uint32_t nbits = min_u32(1u + (x >> (npostfix + 1u)), 24u);
+                    uint32_t extra;
+                    if (nbits <= 17u) { extra = br.peek(nbits); br.consume(nbits); } else extra = br.read(nbits);
+                    const uint32_t hcode = x >> npostfix, lcode = x & ((1u << npostfix) - 1u);
+                    c.dist = ((((2u + (hcode & 1u)) << nbits) - 4u + extra) << npostfix) + lcode + ndirect + 1u;
+                }
+            }
+        }
+    }
+    return c;
+}
+
+// ---- stage: the distance ring (PageDecoder.cpp:345-364, :396-403).  The ring proper lives in registers; the last four
+// distances pushed in a round travel to the next round through LDS (ring_push, two rounds alternate).
+struct DistanceRing {
+    uint32_t r0 = 4, r1 = 11, r2 = 15, r3 = 16;     // PageDecoder.cpp:150-153
+    uint32_t cnt = 0, par = 0;                      // pushes of the previous round still to be folded in, and where they are
+    __device__ __forceinline__ void reset() { r0 = 4; r1 = 11; r2 = 15; r3 = 16; cnt = 0; }
+};
+// the previous round's pushes: read at the top of a round, folded in by resolve_distance_ring
+template <class Lds>
+__device__ __forceinline__ Bytes16 load_ring_pushes(const Lds& L, const DistanceRing& ring)
+{
+    Bytes16 pushed = {0u, 0u, 0u, 0u};
+    if (ring.cnt) pushed = *reinterpret_cast<const Bytes16*>(L.ring_push[ring.par ^ 1u]);
+    return pushed;
+}
+// Codes 1..15 are resolved in command order; explicit distances and code 0 need no serial step.  On return c.dist
+// is final for every copy command of the round.
+template <class Lds>
+__device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring, Bytes16 pushed, RoundCommands& c, uint32_t sl)
+{
+    {   // new ring = the last four pushed distances (PageDecoder.cpp:396-403)
+        const uint32_t o0 = ring.r0, o1 = ring.r1, o2 = ring.r2;
+        if (ring.cnt >= 4u) { ring.r0 = pushed[0]; ring.r1 = pushed[1]; ring.r2 = pushed[2]; ring.r3 = pushed[3]; }
+        else if (ring.cnt == 3u) { ring.r0 = pushed[0]; ring.r1 = pushed[1]; ring.r2 = pushed[2]; ring.r3 = o0; }
+        else if (ring.cnt == 2u) { ring.r0 = pushed[0]; ring.r1 = pushed[1]; ring.r2 = o0; ring.r3 = o1; }
+        else if (ring.cnt == 1u) { ring.r0 = pushed[0]; ring.r1 = o0; ring.r2 = o1; ring.r3 = o2; }
+    }
+    const uint32_t dcode = c.dcode;
+    uint32_t dist = c.dist;
+    const bool is_copy = c.is_cmd && c.copy > 0u;
+    const uint32_t push_mask = wave::half_ballot(is_copy && dcode != 0u);
+    // A code 1..15 refers to the r-th most recent push before the command (r from the code): either
+    // a command of this round (lane `src`) or the ring carried in from earlier rounds.  All lanes
+    // whose source is already known resolve together; a chain of ring codes takes one pass per link
+    // (the lowest unresolved lane is always resolvable).
+    uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
+    {
+        const uint32_t r = dcode < 4u ? dcode : (dcode < 10u ? 0u : 1u);
+        uint32_t below = push_mask & ((1u << sl) - 1u);
+        const uint32_t cnt = (uint32_t)__popc(below);
+        if (r >= 1u && below) below &= ~(1u << msb_u32(below));
+        if (r >= 2u && below) below &= ~(1u << msb_u32(below));
+        if (r >= 3u && below) below &= ~(1u << msb_u32(below));
+        const bool from_round = r < cnt;                            // else: carried ring entry r - cnt
+        const uint32_t src = from_round ? msb_u32(below) : 0u;
+        const uint32_t q = r - cnt;
+        const uint32_t carried = q == 0u ? ring.r0 : q == 1u ? ring.r1 : q == 2u ? ring.r2 : ring.r3;
+        const uint32_t j = dcode >= 4u ? (dcode - 4u) % 6u : 0u, mag = dcode >= 4u ? (j >> 1) + 1u : 0u;
+        while (wave::any(pend != 0u)) {
+            const bool mine = ((pend >> sl) & 1u) != 0u;
+            const bool ready = mine && (!from_round || ((pend >> src) & 1u) == 0u);
+            const uint32_t from = wave::half_shfl(dist, src);
+            if (ready) {
+                const uint32_t val = from_round ? from : carried;
+                dist = (j & 1u) ? val + mag : val - mag;
+            }
+            pend &= ~wave::half_ballot(ready);
+        }
+    }
+    {
+        const uint32_t below = push_mask & ((1u << sl) - 1u);
+        const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
+        if (is_copy && dcode == 0u) dist = below ? from : ring.r0;
+        // the round's last four pushes go to LDS, most recent first; the next round folds them into the ring
+        const bool pusher = is_copy && dcode != 0u;
+        const uint32_t above = (uint32_t)__popc((push_mask >> sl) >> 1);    // pushes after mine
+        if (pusher && above < 4u) L.ring_push[ring.par][above] = dist;
+        ring.cnt = (uint32_t)__popc(push_mask);
+        ring.par ^= 1u;
+    }
+    c.dist = dist;
+}
+
 // The persistent page loop of one wavefront.  Each 32-lane half decodes its own page and takes the
 // next page from the work counter as soon as it is done, independently of the other half: pages
 // differ a lot in their number of rounds (stored, run-length and text pages side by side), and a
@@ -865,8 +1092,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
     }
     BitReader br;
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
-    uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16;             // PageDecoder.cpp:150-153
-    uint32_t ring_cnt = 0, ring_par = 0;    // pushes of the previous round still to be folded into ring0..3, and where they are
+    DistanceRing ring;
     uint32_t out_pos = 0;            // bytes of the page produced so far
     uint32_t prev_tail = 0;          // literals decoded but not yet consumed
     uint32_t carry_head = 0;
@@ -887,75 +1113,10 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             const bool want = !live && !finished && other_near == 0u;
             if (wave::any(want)) {
                 clk.lap(kPhDelta);
-                const uint32_t total = a.page_base[a.num_streams];
-                const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
-                uint32_t* const work_counter = a.work_counter;
-                // Stored pages (PageDecoder.cpp:70-76) are copied on the spot and rejected ones skipped: a
-                // half keeps taking pages until it holds a compressed one, so that both halves reach the
-                // table build together.
-                bool need = want, start = false;
-                while (wave::any(need)) {
-                    uint32_t g = 0;
-                    if (need && sl == 0u) g = atomicAdd(work_counter, 1u);
-                    g = wave::half_bcast(g, 0u);
-                    const bool got = need && g < total;
-                    if (need && !got) { finished = true; need = false; }
-                    {
-                        const PageJob nj = fetch_job(a, order, g, got);
-                        if (got) job = nj;
-                    }
-                    const bool fresh = got && job.valid;
-                    const bool stored = fresh && job.in_size == job.out_size;
-                    if (stored) {                                       // plain copy, 4 bytes per lane per step
-                        const uint32_t words = job.out_size >> 2;
-                        for (uint32_t i = sl; i < words; i += 32u)
-                            reinterpret_cast<uint32_t*>(job.out)[i] = load_u32(job.in + 4u * i);
-                        for (uint32_t i = (words << 2) + sl; i < job.out_size; i += 32u) job.out[i] = job.in[i];
-                    }
-                    if (fresh && !stored) { start = true; need = false; }
-                }
-
-                // ---- page header + sub-stream size table (PageDecoder.cpp:79-121)
-                {
-                    uint32_t my_len = 0, hdr_bytes = 0;
-                    if (start) {
-                        const uint32_t w0 = br_load(job, 0u), w1 = br_load(job, 4u);
-                        const uint64_t h = (uint64_t)w0 | ((uint64_t)w1 << 32);
-                        const uint32_t npostfix = (uint32_t)h & 3u;
-                        const uint32_t is_delta = ((((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr) ? 1u : 0u;   // PageDecoder.cpp:87-88
-                        // kept in LDS rather than in a register for the whole page: read once per round at most
-                        if (sl == 0u) L.page_params = npostfix | ((((uint32_t)h >> 2) & 15u) << (npostfix + 8u)) | (is_delta << 16);
-                        const uint32_t base_bits = bit_width_u32((job.in_size + 31u) / 32u);
-                        const uint32_t dsize_bits = bit_width_u32(bit_width_u32(job.in_size - 1u));
-                        const uint32_t base_size = (uint32_t)(h >> 8) & ((1u << base_bits) - 1u);
-                        const uint32_t delta_bits = (uint32_t)(h >> (8u + base_bits)) & ((1u << dsize_bits) - 1u);
-                        const uint32_t table_at = 8u + base_bits + dsize_bits;
-                        const uint32_t bit = table_at + sl * delta_bits;
-                        const uint32_t wi = (bit >> 5) * 4u;
-                        const uint64_t d = (uint64_t)br_load(job, wi) | ((uint64_t)br_load(job, wi + 4u) << 32);
-                        const uint32_t delta = (uint32_t)(d >> (bit & 31u)) & ((1u << delta_bits) - 1u);
-                        my_len = base_size + delta;
-                        hdr_bytes = ((table_at + 32u * delta_bits + 31u) / 32u) * 4u;
-                    }
-                    const uint32_t incl = wave::half_scan_incl(my_len);
-                    if (start) br.init(job.in, job.in_limit, hdr_bytes + incl - my_len);
-                }
-                clk.lap(kPhSetup);
-                // one copy of the table builder in the instruction stream, run three times (ICP, distance, literal):
-                // inlined three times it was most of the kernel's code size, beyond what the instruction cache holds
                 bool tables_ok = true;
-#pragma nounroll
-                for (uint32_t k = 0; k < 3u; ++k) {
-                    const TableRef t{k == 0u ? L.lut_icp : k == 1u ? L.lut_dist : L.lut_lit,
-                                     k == 0u ? L.sorted_icp : k == 1u ? L.sorted_dist : L.sorted_lit,
-                                     L.limit[k], L.first_offs[k],
-                                     k == 0u ? kIcpAlphabet : k == 1u ? kDistAlphabet : kLitAlphabet,
-                                     k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit, far_syms};
-                    const bool ok = build_table(t, L.win, br, start, sl);      // the window holds the code lengths meanwhile
-                    tables_ok = tables_ok && ok;
-                }
+                const bool start = start_pages(a, L, job, br, want, finished, sl, far_syms, tables_ok, [](const PageJob&) {}, clk);
                 if (start) {
-                    ring0 = 4; ring1 = 11; ring2 = 15; ring3 = 16; ring_cnt = 0;
+                    ring.reset();
                     out_pos = 0; prev_tail = 0; carry_head = 0; flushed = 0; bad = false;
                     view.win_base = 0u;
                     live = true;
@@ -971,59 +1132,11 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
 
         // ---- rounds (PageDecoder.cpp:174-236; format A.6) until a page ends
         do {
-        // -- 1. one command per lane.  Two refill points per command: with >= 32 bits in the window the
-        //       command symbol (<= 15 bits) leaves >= 17 for the insert/copy extra bits, and likewise the
-        //       distance symbol for its extra bits; longer fields (rare) take the general read.
-        // the distances pushed in the previous round (written to LDS by their lanes at the end of its ring step):
-        // read now, folded into the ring when it is needed below
-        Bytes16 pushed = {0u, 0u, 0u, 0u};
-        if (ring_cnt) pushed = *reinterpret_cast<const Bytes16*>(L.ring_push[ring_par ^ 1u]);
-        uint32_t sym = 0, len = 0;
-        if (live) { br.ensure(32); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
-        clk.lap(kPhCmdSym);
-        const uint32_t sent_mask = wave::half_ballot(live && sym == kSentinel);
-        const uint32_t n = sent_mask ? ctz_u32(sent_mask) : 32u;
-        const bool is_cmd = live && sl < n;
-        if (live && sl <= n) br.consume(len);                           // the sentinel's own bits are consumed too
-
-        uint32_t ins = 0, copy = 0, dist = 0, dcode = 0;
-        if (is_cmd) {
-            // insert and copy length codes (for insert-only symbols 705..727 the copy length stays 0)
-            const bool has_copy = sym < kSentinel;
-            const uint32_t cell = sym >> 6;
-            const uint32_t ic = has_copy ? ((0x298500u >> (2u * cell)) & 3u) * 8u + ((sym >> 3) & 7u) : min_u32(sym - kSentinel, 23u);
-            const uint32_t cc = ((0x262444u >> (2u * cell)) & 3u) * 8u + (sym & 7u);
-            const uint32_t it = W.len_code_tab[ic], ct = has_copy ? W.len_code_tab[24u + cc] : 0u;
-            const uint32_t ie = it >> 16, ce = ct >> 16;
-            uint32_t xi, xc;
-            if (ie + ce <= 17u) {                                       // both fields are already in the window
-                const uint32_t x = br.peek(ie + ce);
-                br.consume(ie + ce);
-                xi = x & ((1u << ie) - 1u); xc = x >> ie;
-            } else { xi = br.read(ie); xc = br.read(ce); }
-            ins = (it & 0xFFFFu) + xi;
-            copy = has_copy ? (ct & 0xFFFFu) + xc : 0u;
-            clk.lap(kPhCmdExtra);
-            if (has_copy && sym >= 128u) {                              // explicit distance symbol
-                uint32_t dl;
-                br.ensure(32);
-                dcode = decode_symbol<kLutBitsDist>(t_dist, br, dl);
-                br.consume(dl);
-                if (dcode >= 16u) {                                     // PageDecoder.cpp:365-390
-                    const uint32_t pp = L.page_params;
-                    const uint32_t npostfix = pp & 3u, ndirect = (pp >> 8) & 0xFFu;
-                    if (dcode < 16u + ndirect) dist = dcode - 15u;
-                    else {
-                        const uint32_t x = dcode - ndirect - 16u;
-                        const uint32_t nbits = min_u32(1u + (x >> (npostfix + 1u)), 24u);
-                        uint32_t extra;
-                        if (nbits <= 17u) { extra = br.peek(nbits); br.consume(nbits); } else extra = br.read(nbits);
-                        const uint32_t hcode = x >> npostfix, lcode = x & ((1u << npostfix) - 1u);
-                        dist = ((((2u + (hcode & 1u)) << nbits) - 4u + extra) << npostfix) + lcode + ndirect + 1u;
-                    }
-                }
-            }
-        }
+        // -- 1. one command per lane (the previous round's ring pushes are requested first: they are needed in step 2)
+        const Bytes16 pushed = load_ring_pushes(L, ring);
+        RoundCommands cmd = decode_round_commands(L, W.len_code_tab, t_icp, t_dist, br, live, sl, clk);
+        const uint32_t sent_mask = cmd.sent_mask, n = cmd.n;
+        const bool is_cmd = cmd.is_cmd;
 
         clk.lap(kPhCommands);
         clk.count(kPhRounds, 1);
@@ -1031,56 +1144,9 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             const uint64_t lm = wave::ballot64(live);
             clk.count(kPhSlow, (((uint32_t)lm != 0u) != ((uint32_t)(lm >> 32) != 0u)) ? 1u : 0u);
         }
-        // -- 2. distance ring (PageDecoder.cpp:345-364, :396-403): codes 1..15 are resolved in
-        //       command order; explicit distances and code 0 need no serial step
-        {   // new ring = the last four pushed distances (PageDecoder.cpp:396-403)
-            const uint32_t o0 = ring0, o1 = ring1, o2 = ring2;
-            if (ring_cnt >= 4u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = pushed[2]; ring3 = pushed[3]; }
-            else if (ring_cnt == 3u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = pushed[2]; ring3 = o0; }
-            else if (ring_cnt == 2u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = o0; ring3 = o1; }
-            else if (ring_cnt == 1u) { ring0 = pushed[0]; ring1 = o0; ring2 = o1; ring3 = o2; }
-        }
-        const bool is_copy = is_cmd && copy > 0u;
-        const uint32_t push_mask = wave::half_ballot(is_copy && dcode != 0u);
-        // A code 1..15 refers to the r-th most recent push before the command (r from the code): either
-        // a command of this round (lane `src`) or the ring carried in from earlier rounds.  All lanes
-        // whose source is already known resolve together; a chain of ring codes takes one pass per link
-        // (the lowest unresolved lane is always resolvable).
-        uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
-        {
-            const uint32_t r = dcode < 4u ? dcode : (dcode < 10u ? 0u : 1u);
-            uint32_t below = push_mask & ((1u << sl) - 1u);
-            const uint32_t cnt = (uint32_t)__popc(below);
-            if (r >= 1u && below) below &= ~(1u << msb_u32(below));
-            if (r >= 2u && below) below &= ~(1u << msb_u32(below));
-            if (r >= 3u && below) below &= ~(1u << msb_u32(below));
-            const bool from_round = r < cnt;                            // else: carried ring entry r - cnt
-            const uint32_t src = from_round ? msb_u32(below) : 0u;
-            const uint32_t q = r - cnt;
-            const uint32_t carried = q == 0u ? ring0 : q == 1u ? ring1 : q == 2u ? ring2 : ring3;
-            const uint32_t j = dcode >= 4u ? (dcode - 4u) % 6u : 0u, mag = dcode >= 4u ? (j >> 1) + 1u : 0u;
-            while (wave::any(pend != 0u)) {
-                const bool mine = ((pend >> sl) & 1u) != 0u;
-                const bool ready = mine && (!from_round || ((pend >> src) & 1u) == 0u);
-                const uint32_t from = wave::half_shfl(dist, src);
-                if (ready) {
-                    const uint32_t val = from_round ? from : carried;
-                    dist = (j & 1u) ? val + mag : val - mag;
-                }
-                pend &= ~wave::half_ballot(ready);
-            }
-        }
-        {
-            const uint32_t below = push_mask & ((1u << sl) - 1u);
-            const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
-            if (is_copy && dcode == 0u) dist = below ? from : ring0;
-            // the round's last four pushes go to LDS, most recent first; the next round folds them into the ring
-            const bool pusher = is_copy && dcode != 0u;
-            const uint32_t above = (uint32_t)__popc((push_mask >> sl) >> 1);    // pushes after mine
-            if (pusher && above < 4u) L.ring_push[ring_par][above] = dist;
-            ring_cnt = (uint32_t)__popc(push_mask);
-            ring_par ^= 1u;
-        }
+        // -- 2. distance ring
+        resolve_distance_ring(L, ring, pushed, cmd, sl);
+        const uint32_t ins = cmd.ins, copy = cmd.copy, dist = cmd.dist;
 
         clk.lap(kPhRing);
         // -- 3. output positions

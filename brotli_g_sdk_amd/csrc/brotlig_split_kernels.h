@@ -64,6 +64,11 @@ static_assert(kLutBitsIcp == 8 && kLutBitsDist == 8 && kLutBitsLit == 8, "build 
 static_assert(__builtin_offsetof(EntropyLds, build_tail) == 1536 && __builtin_offsetof(EntropyLds, lit_lens) == 1536 + 544, "build areas must follow the LUTs");
 static_assert(512 + 544 >= kIcpAlphabet && 544 >= kDistAlphabet, "code lengths fit their build areas");
 
+__device__ __forceinline__ uint8_t* build_lens(EntropyLds& L, uint32_t k)
+{
+    return k == 0u ? reinterpret_cast<uint8_t*>(L.lut_lit) : k == 1u ? L.build_tail : L.lit_lens;
+}
+
 struct __attribute__((aligned(16))) EntropyWaveLds {
     EntropyLds page[2];
     uint32_t len_code_tab[48];
@@ -84,7 +89,8 @@ __device__ inline void entropy_pages(EntropyWaveLds& W, const DecodeArgs& a)
     bool live = false, finished = false, bad = false;
     BitReader br;
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
-    uint32_t ring0 = 4, ring1 = 11, ring2 = 15, ring3 = 16, ring_cnt = 0, ring_par = 0;
+    DistanceRing ring;
+    PhaseClock<false> clk;
     uint32_t out_pos = 0;            // bytes of the page accounted for so far
     uint32_t lit_pos = 0;            // literals consumed so far (sum of insert lengths)
     uint32_t prev_tail = 0;          // literals decoded but not yet consumed: the literal array holds lit_pos + prev_tail bytes
@@ -98,69 +104,13 @@ __device__ inline void entropy_pages(EntropyWaveLds& W, const DecodeArgs& a)
             const uint32_t other_near = wave::other_half(near_end);
             const bool want = !live && !finished && other_near == 0u;
             if (wave::any(want)) {
-                const uint32_t total = a.page_base[a.num_streams];
-                const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
-                uint32_t* const work_counter = a.work_counter;
-                bool need = want, start = false;
-                while (wave::any(need)) {
-                    uint32_t g = 0;
-                    if (need && sl == 0u) g = atomicAdd(work_counter, 1u);
-                    g = wave::half_bcast(g, 0u);
-                    const bool got = need && g < total;
-                    if (need && !got) { finished = true; need = false; }
-                    {
-                        const PageJob nj = fetch_job(a, order, g, got);
-                        if (got) job = nj;
-                    }
-                    const bool fresh = got && job.valid;
-                    const bool stored = fresh && job.in_size == job.out_size;
-                    if (got && sl == 0u) a.slot_hdr[2u * job.index + 1u] = 0u;     // nothing for the assembly kernel (yet)
-                    if (stored) {                                       // PageDecoder.cpp:70-76: plain copy, here and now
-                        const uint32_t words = job.out_size >> 2;
-                        for (uint32_t i = sl; i < words; i += 32u)
-                            reinterpret_cast<uint32_t*>(job.out)[i] = load_u32(job.in + 4u * i);
-                        for (uint32_t i = (words << 2) + sl; i < job.out_size; i += 32u) job.out[i] = job.in[i];
-                    }
-                    if (fresh && !stored) { start = true; need = false; }
-                }
-                // page header + sub-stream size table (PageDecoder.cpp:79-121)
-                {
-                    uint32_t my_len = 0, hdr_bytes = 0;
-                    if (start) {
-                        const uint32_t w0 = br_load(job, 0u), w1 = br_load(job, 4u);
-                        const uint64_t h = (uint64_t)w0 | ((uint64_t)w1 << 32);
-                        const uint32_t npostfix = (uint32_t)h & 3u;
-                        const uint32_t is_delta = ((((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr) ? 1u : 0u;
-                        if (sl == 0u) L.page_params = npostfix | ((((uint32_t)h >> 2) & 15u) << (npostfix + 8u)) | (is_delta << 16);
-                        const uint32_t base_bits = bit_width_u32((job.in_size + 31u) / 32u);
-                        const uint32_t dsize_bits = bit_width_u32(bit_width_u32(job.in_size - 1u));
-                        const uint32_t base_size = (uint32_t)(h >> 8) & ((1u << base_bits) - 1u);
-                        const uint32_t delta_bits = (uint32_t)(h >> (8u + base_bits)) & ((1u << dsize_bits) - 1u);
-                        const uint32_t table_at = 8u + base_bits + dsize_bits;
-                        const uint32_t bit = table_at + sl * delta_bits;
-                        const uint32_t wi = (bit >> 5) * 4u;
-                        const uint64_t d = (uint64_t)br_load(job, wi) | ((uint64_t)br_load(job, wi + 4u) << 32);
-                        const uint32_t delta = (uint32_t)(d >> (bit & 31u)) & ((1u << delta_bits) - 1u);
-                        my_len = base_size + delta;
-                        hdr_bytes = ((table_at + 32u * delta_bits + 31u) / 32u) * 4u;
-                    }
-                    const uint32_t incl = wave::half_scan_incl(my_len);
-                    if (start) br.init(job.in, job.in_limit, hdr_bytes + incl - my_len);
-                }
                 bool tables_ok = true;
-#pragma nounroll
-                for (uint32_t k = 0; k < 3u; ++k) {
-                    const TableRef t{k == 0u ? L.lut_icp : k == 1u ? L.lut_dist : L.lut_lit,
-                                     k == 0u ? L.sorted_icp : k == 1u ? L.sorted_dist : L.sorted_lit,
-                                     L.limit[k], L.first_offs[k],
-                                     k == 0u ? kIcpAlphabet : k == 1u ? kDistAlphabet : kLitAlphabet,
-                                     k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit, far_syms};
-                    uint8_t* const lens = k == 0u ? reinterpret_cast<uint8_t*>(L.lut_lit) : k == 1u ? L.build_tail : L.lit_lens;
-                    const bool ok = build_table(t, lens, br, start, sl);
-                    tables_ok = tables_ok && ok;
-                }
+                uint32_t* const slot_hdr = a.slot_hdr;
+                const bool start = start_pages(a, L, job, br, want, finished, sl, far_syms, tables_ok,
+                                               [slot_hdr, sl](const PageJob& j) { if (sl == 0u) slot_hdr[2u * j.index + 1u] = 0u; },   // nothing for the assembly kernel (yet)
+                                               clk);
                 if (start) {
-                    ring0 = 4; ring1 = 11; ring2 = 15; ring3 = 16; ring_cnt = 0;
+                    ring.reset();
                     out_pos = 0; lit_pos = 0; prev_tail = 0; cmd_count = 0; bad = false;
                     live = true;
                     if (!tables_ok) { bad = true; out_pos = job.out_size; }     // first round is refused (or a bare sentinel)
@@ -173,96 +123,12 @@ __device__ inline void entropy_pages(EntropyWaveLds& W, const DecodeArgs& a)
         uint8_t* const my_lits = a.lits + (size_t)job.index * a.lit_stride;
 
         do {
-        // -- 1. one command per lane (PageDecoder.cpp:290-320)
-        Bytes16 pushed = {0u, 0u, 0u, 0u};
-        if (ring_cnt) pushed = *reinterpret_cast<const Bytes16*>(L.ring_push[ring_par ^ 1u]);
-        uint32_t sym = 0, len = 0;
-        if (live) { br.ensure(32); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
-        const uint32_t sent_mask = wave::half_ballot(live && sym == kSentinel);
-        const uint32_t n = sent_mask ? ctz_u32(sent_mask) : 32u;
-        const bool is_cmd = live && sl < n;
-        if (live && sl <= n) br.consume(len);
-
-        uint32_t ins = 0, copy = 0, dist = 0, dcode = 0;
-        if (is_cmd) {
-            const bool has_copy = sym < kSentinel;
-            const uint32_t cell = sym >> 6;
-            const uint32_t ic = has_copy ? ((0x298500u >> (2u * cell)) & 3u) * 8u + ((sym >> 3) & 7u) : min_u32(sym - kSentinel, 23u);
-            const uint32_t cc = ((0x262444u >> (2u * cell)) & 3u) * 8u + (sym & 7u);
-            const uint32_t it = W.len_code_tab[ic], ct = has_copy ? W.len_code_tab[24u + cc] : 0u;
-            const uint32_t ie = it >> 16, ce = ct >> 16;
-            uint32_t xi, xc;
-            if (ie + ce <= 17u) {
-                const uint32_t x = br.peek(ie + ce);
-                br.consume(ie + ce);
-                xi = x & ((1u << ie) - 1u); xc = x >> ie;
-            } else { xi = br.read(ie); xc = br.read(ce); }
-            ins = (it & 0xFFFFu) + xi;
-            copy = has_copy ? (ct & 0xFFFFu) + xc : 0u;
-            if (has_copy && sym >= 128u) {                              // explicit distance symbol (PageDecoder.cpp:338-404)
-                uint32_t dl;
-                br.ensure(32);
-                dcode = decode_symbol<kLutBitsDist>(t_dist, br, dl);
-                br.consume(dl);
-                if (dcode >= 16u) {
-                    const uint32_t pp = L.page_params;
-                    const uint32_t npostfix = pp & 3u, ndirect = (pp >> 8) & 0xFFu;
-                    if (dcode < 16u + ndirect) dist = dcode - 15u;
-                    else {
-                        const uint32_t x = dcode - ndirect - 16u;
-                        const uint32_t nbits = min_u32(1u + (x >> (npostfix + 1u)), 24u);
-                        uint32_t extra;
-                        if (nbits <= 17u) { extra = br.peek(nbits); br.consume(nbits); } else extra = br.read(nbits);
-                        const uint32_t hcode = x >> npostfix, lcode = x & ((1u << npostfix) - 1u);
-                        dist = ((((2u + (hcode & 1u)) << nbits) - 4u + extra) << npostfix) + lcode + ndirect + 1u;
-                    }
-                }
-            }
-        }
-        // -- 2. distance ring (as in the fused kernel)
-        {
-            const uint32_t o0 = ring0, o1 = ring1, o2 = ring2;
-            if (ring_cnt >= 4u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = pushed[2]; ring3 = pushed[3]; }
-            else if (ring_cnt == 3u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = pushed[2]; ring3 = o0; }
-            else if (ring_cnt == 2u) { ring0 = pushed[0]; ring1 = pushed[1]; ring2 = o0; ring3 = o1; }
-            else if (ring_cnt == 1u) { ring0 = pushed[0]; ring1 = o0; ring2 = o1; ring3 = o2; }
-        }
-        const bool is_copy = is_cmd && copy > 0u;
-        const uint32_t push_mask = wave::half_ballot(is_copy && dcode != 0u);
-        uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
-        {
-            const uint32_t r = dcode < 4u ? dcode : (dcode < 10u ? 0u : 1u);
-            uint32_t below = push_mask & ((1u << sl) - 1u);
-            const uint32_t cnt = (uint32_t)__popc(below);
-            if (r >= 1u && below) below &= ~(1u << msb_u32(below));
-            if (r >= 2u && below) below &= ~(1u << msb_u32(below));
-            if (r >= 3u && below) below &= ~(1u << msb_u32(below));
-            const bool from_round = r < cnt;
-            const uint32_t src = from_round ? msb_u32(below) : 0u;
-            const uint32_t q = r - cnt;
-            const uint32_t carried = q == 0u ? ring0 : q == 1u ? ring1 : q == 2u ? ring2 : ring3;
-            const uint32_t j = dcode >= 4u ? (dcode - 4u) % 6u : 0u, mag = dcode >= 4u ? (j >> 1) + 1u : 0u;
-            while (wave::any(pend != 0u)) {
-                const bool mine = ((pend >> sl) & 1u) != 0u;
-                const bool ready = mine && (!from_round || ((pend >> src) & 1u) == 0u);
-                const uint32_t from = wave::half_shfl(dist, src);
-                if (ready) {
-                    const uint32_t val = from_round ? from : carried;
-                    dist = (j & 1u) ? val + mag : val - mag;
-                }
-                pend &= ~wave::half_ballot(ready);
-            }
-        }
-        {
-            const uint32_t below = push_mask & ((1u << sl) - 1u);
-            const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
-            if (is_copy && dcode == 0u) dist = below ? from : ring0;
-            const bool pusher = is_copy && dcode != 0u;
-            const uint32_t above = (uint32_t)__popc((push_mask >> sl) >> 1);
-            if (pusher && above < 4u) L.ring_push[ring_par][above] = dist;
-            ring_cnt = (uint32_t)__popc(push_mask);
-            ring_par ^= 1u;
-        }
+        // -- 1. one command per lane, 2. the distance ring (stages shared with the fused kernel)
+        const Bytes16 pushed = load_ring_pushes(L, ring);
+        RoundCommands cmd = decode_round_commands(L, W.len_code_tab, t_icp, t_dist, br, live, sl, clk);
+        resolve_distance_ring(L, ring, pushed, cmd, sl);
+        const uint32_t sent_mask = cmd.sent_mask, n = cmd.n, ins = cmd.ins, copy = cmd.copy, dist = cmd.dist;
+        const bool is_cmd = cmd.is_cmd;
         // -- 3. positions, and the checks that keep the assembly kernel inside its page
         const uint32_t tot = ins + copy;
         const uint32_t incl_tot = wave::half_scan_incl(tot);
