@@ -144,7 +144,7 @@ template <> struct PhaseClock<true> {
 #define BROTLIG_ABLATE 0
 #endif
 enum : uint32_t { kAblLevels = 1u, kAblTeams = 2u, kAblOverlap = 4u, kAblFar = 8u, kAblSlide = 16u, kAblDeps = 32u, kAblLitStore = 64u,
-                  kAblOwnLane = 128u, kExpNoB = 256u };
+                  kAblOwnLane = 128u };
 constexpr uint32_t kAblate = BROTLIG_ABLATE;
 
 // ---- tunables ---------------------------------------------------------------------------
@@ -178,11 +178,6 @@ constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the 
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
 constexpr uint32_t kShortCopy = BROTLIG_TUNE_SHORT_COPY;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
 constexpr uint32_t kOwnCopy = BROTLIG_TUNE_OWN_COPY;             // simple copies up to this length run one-lane-per-command (batches of four 8-byte chunks)
-#ifndef BROTLIG_FORWARD_HOPS
-#define BROTLIG_FORWARD_HOPS 0
-#endif
-constexpr uint32_t kForwardHops = BROTLIG_FORWARD_HOPS;     // source forwarding through this many earlier copies (0 = off: it removes
-                                                            // 15 % of the dependency levels and costs as much as it saves)
 // Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
 // between copies); bytes older than the window are read back from global memory.  The window is
@@ -532,8 +527,8 @@ __device__ __forceinline__ void table_set_sym(const TableRef& t, uint32_t i, uin
 // the limits of lengths 8..15 arrive in one aligned 16-byte LDS read (same address for the whole
 // half), the length is a count of compares, then one read for {first code, offset} and one for the
 // symbol -- two dependent reads instead of a search loop.
-template <int kBits>
-__device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitReader& br, uint32_t& len)
+template <int kBits, class Reader>
+__device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const Reader& br, uint32_t& len)
 {
     static_assert(kBits >= 7 && kBits <= 14, "limit words 8..15 must cover every long length");
     const uint32_t bits = (uint32_t)br.buf;
@@ -569,7 +564,8 @@ __device__ __forceinline__ uint32_t decode_symbol(const TableRef& t, const BitRe
 // whether this half has a compressed page; `codelens` = alphabet bytes of LDS for the code lengths.  Returns false for a description the format does not define (the page
 // is then rejected): a `simple` code of one symbol, for which the reference indexes FixedCodelengths[-1]
 // (BrotligHuffmanTable.cpp:103); DecodeCPU (csrc/brotlig_cpu.cpp) rejects the same.
-__device__ inline bool build_table(const TableRef& t, uint8_t* codelens, BitReader& br, bool live, uint32_t sl)
+template <class Reader>
+__device__ inline bool build_table(const TableRef& t, uint8_t* codelens, Reader& br, bool live, uint32_t sl)
 {
     const uint32_t A = t.alphabet;
     const uint32_t maxbits = bit_width_u32(A - 1u);
@@ -828,6 +824,351 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
     return job;
 }
 
+// ---- stage: flush and slide of the output window, at the start of a group whose first byte is page position `gpos` and
+// whose last is `gend - 1`.  Every group first stores the finished bytes below it (aligned 16-byte pieces; `flushed` is
+// 16-byte aligned until the page's last flush and at most kRoundMax + 15 bytes behind), so that a far copy -- source
+// below the window, i.e. more than kHist >= kRoundMax + 16 bytes back -- only ever reads global memory written by an
+// EARLIER group's flush.  When the group does not fit behind what the window holds, the window slides: kHist .. kHist + 15
+// bytes of history are kept and brought down in one step, all reads before the writes.
+__device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed, uint8_t* out, bool on, uint32_t gpos, uint32_t gend, uint32_t sl)
+{
+    const bool slide = on && gend > view.win_base + kWin && !(kAblate & kAblSlide);
+    wave::sync();
+    {
+        const uint32_t e16 = gpos & ~15u;
+        const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
+        const bool f0 = on && p0 < e16, f1 = on && p1 < e16;
+        Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0;
+        if (f0) a0 = load16(view.win + (p0 - view.win_base));
+        if (f1) a1 = load16(view.win + (p1 - view.win_base));
+        if (f0) store16(out + p0, a0);
+        if (f1) store16(out + p1, a1);
+        if (on && e16 > flushed) flushed = e16;
+    }
+    if (wave::any(slide)) {
+        const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
+        const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
+        const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
+        Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0;
+        if (i0 < count) m0 = load16(view.win + shift + i0);
+        if (i1 < count) m1 = load16(view.win + shift + i1);
+        wave::sync();
+        if (i0 < count) store16(view.win + i0, m0);
+        if (i1 < count) store16(view.win + i1, m1);
+        view.win_base = nb;
+    }
+    wave::sync();
+}
+
+// ---- stage: the LZ77 copies of a group in dependency levels (PageDecoder.cpp:219-232 / BrotliGCompute.hlsl:1401-1419).
+// One piece per lane: `plen` bytes to window index dst_idx from `dist` bytes back; the first far_len bytes of its pattern
+// come from the staging area at stage_off (far sources, stored there before the call), the rest from the window at src_idx.
+// A piece runs as soon as none of the pieces its source overlaps is still unfinished (dep_mask: lanes of the half).  A
+// level without long pieces runs one lane per piece; otherwise the ready pieces share the 32 lanes as teams, 8 bytes per
+// lane per step.  Overlapping copies replay their pattern modulo the distance, so a copy never waits for itself.
+// Pieces with `far_direct` went from registers straight to their place and take no part.
+template <class Clock>
+__device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage, uint32_t plen, uint32_t dist, uint32_t far_len, uint32_t stage_off,
+                                            uint32_t src_idx, uint32_t dst_idx, bool far_direct, uint32_t dep_mask, uint32_t sl, Clock& clk)
+{
+    const uint32_t pattern = min_u32(plen, dist);
+    const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
+    const uint32_t packed = plen | (far_len << 11) | ((stage_off >> 3) << 22);
+    // simple piece: pattern in one place (window or staging area) and no chunk of a 32-byte batch reads
+    // what an earlier chunk of the batch wrote
+    const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
+    uint32_t todo = wave::half_ballot(plen != 0u && !far_direct && !(kAblate & kAblLevels));
+    while (wave::any(todo != 0u)) {
+        clk.count(kPhLevels, 1);
+        clk.halves(kPhLevelHalves, todo != 0u);
+        const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
+        const uint32_t ready_mask = wave::half_ballot(ready);
+        if ((kAblate & kAblTeams) || !wave::any(ready && (plen > (simple ? kOwnCopy : kShortCopy)))) {
+            // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
+            // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
+            // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
+            // wrote, and every byte loaded belongs to the source (a piece ready in this level never
+            // has another ready piece inside its source).
+            const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx;
+            uint8_t* dp = win + dst_idx;
+            const bool whole = far_len == 0u || far_len == pattern;
+            const bool lane_a = ready && simple && !(kAblate & kAblOwnLane);
+            const bool lane_b = ready && !simple && !(kAblate & kAblOverlap);
+            if (lane_a) {
+                if (plen >= 8u) {
+                    const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
+                    uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
+                    v0 = load_u64u(sp);
+                    if (plen > 8u) v1 = load_u64u(sp + c1);
+                    if (plen > 16u) v2 = load_u64u(sp + c2);
+                    if (plen > 24u) v3 = load_u64u(sp + c3);
+                    __builtin_memcpy(dp, &v0, 8);
+                    if (plen > 8u) __builtin_memcpy(dp + c1, &v1, 8);
+                    if (plen > 16u) __builtin_memcpy(dp + c2, &v2, 8);
+                    if (plen > 24u) __builtin_memcpy(dp + c3, &v3, 8);
+                } else {
+                    store_bytes(dp, load_u64u(sp), plen);
+                }
+            }
+            for (uint32_t o = 32u; wave::any(lane_a && plen > o); o += 32u) {      // further batches: bytes o .. min(o + 32, plen) - 1
+                if (lane_a && plen > o) {
+                    const uint32_t c0 = min_u32(o, clip8), c1 = min_u32(o + 8u, clip8), c2 = min_u32(o + 16u, clip8), c3 = min_u32(o + 24u, clip8);
+                    uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
+                    v0 = load_u64u(sp + c0);
+                    if (plen > o + 8u) v1 = load_u64u(sp + c1);
+                    if (plen > o + 16u) v2 = load_u64u(sp + c2);
+                    if (plen > o + 24u) v3 = load_u64u(sp + c3);
+                    __builtin_memcpy(dp + c0, &v0, 8);
+                    if (plen > o + 8u) __builtin_memcpy(dp + c1, &v1, 8);
+                    if (plen > o + 16u) __builtin_memcpy(dp + c2, &v2, 8);
+                    if (plen > o + 24u) __builtin_memcpy(dp + c3, &v3, 8);
+                }
+            }
+            clk.lap(kPhLvShort);
+            if (wave::any(lane_b)) {
+                // The rest.  Self-overlapping pieces with a distance below 32 are copied forward in
+                // 8-byte chunks from `dd` bytes back, each chunk reading what its predecessors wrote
+                // (LDS accesses of a wave execute in order); a distance below 8 first lays down eight
+                // bytes of its pattern and then continues from the smallest multiple of itself that is
+                // >= 8 (8 - dd >= -dist: the read never reaches below the pattern).  Patterns that
+                // straddle the window boundary go byte by byte.
+                const uint8_t* own_stage = reinterpret_cast<const uint8_t*>(stage) + stage_off;
+                const uint8_t* own_win = win + (int32_t)src_idx;
+                uint32_t dd = dist, o0 = 0u, r = 0u;
+                if (lane_b && whole && dist < 8u) {
+                    store_bytes(dp, pattern_source8(sp, dist, 0u), plen);
+                    dd = (uint32_t)(0x0E0C0A0809080800ull >> (8u * dist)) & 0xFFu;     // 8, 8, 9, 8, 10, 12, 14 for 1..7
+                    o0 = 8u;
+                }
+                for (uint32_t o = o0; wave::any(lane_b && o < plen); o += 8u) {
+                    if (lane_b && o < plen) {
+                        uint64_t v;
+                        if (whole) v = load_u64u(dp + o - dd);
+                        else {
+                            v = 0;
+                            uint32_t rr = r;
+                            for (uint32_t b = 0; b < 8u; ++b) {
+                                const uint64_t x = rr < far_len ? own_stage[rr] : own_win[rr];
+                                v |= x << (8u * b);
+                                rr = rr + 1u == dist ? 0u : rr + 1u;
+                            }
+                            r = advance_mod(r, 8u, dist);
+                        }
+                        store_bytes(dp + o, v, plen - o);
+                    }
+                }
+                clk.lap(kPhLvOverlap);
+            }
+        } else {
+        clk.count(kPhTeamLevels, 1);
+        const Team t = make_team(ready_mask, sl);
+        const uint32_t t_pk = wave::half_shfl(packed, t.job), t_dist = wave::half_shfl(dist, t.job);
+        const uint32_t t_src = wave::half_shfl(src_idx, t.job), t_dst = wave::half_shfl(dst_idx, t.job);
+        const uint32_t t_len = t_pk & 0x7FFu, t_far = (t_pk >> 11) & 0x7FFu;
+        const uint8_t* t_stage = reinterpret_cast<const uint8_t*>(stage) + ((t_pk >> 22) << 3);
+        const uint8_t* t_win = win + (int32_t)t_src;
+        uint8_t* t_out = win + t_dst;
+        const bool act = t.serves && ready_mask != 0u;
+        const uint32_t t_pat = t_dist < t_len ? t_dist : t_len;
+        const bool whole = t_far == 0u || t_far == t_pat;    // pattern in one place (window or staging area)
+        const uint8_t* t_base = t_far ? t_stage : t_win;
+        const bool overlap = t_dist < t_len;
+        clk.lap(kPhLvShort);
+        for (uint32_t c = t.member; wave::any(act && 8u * c < t_len); c += 1u << t.log2_size) {
+            const uint32_t j = 8u * c;
+            if (act && j < t_len) {
+                uint32_t r = j;
+                if (overlap) r = mod_u16(j, t_dist);
+                uint64_t v;
+                if (whole) v = pattern_source8(t_base, t_dist, r);
+                else {                                      // pattern straddles the window boundary: byte by byte
+                    v = 0;
+                    uint32_t rr = r;
+                    for (uint32_t b = 0; b < 8u; ++b) {
+                        const uint32_t x = rr < t_far ? t_stage[rr] : t_win[rr];
+                        v |= (uint64_t)x << (8u * b);
+                        rr = rr + 1u == t_dist ? 0u : rr + 1u;
+                    }
+                }
+                store_bytes(t_out + j, v, t_len - j);
+            }
+            wave::sync();
+        }
+        clk.lap(kPhLvBytes);
+        }
+        todo &= ~ready_mask;
+        wave::sync();
+    }
+}
+
+// ---- stage: per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): a running byte sum over each
+// colour range inside the page, in place in global memory, for the halves with `do_delta`.  16 bytes per lane and step,
+// 512 contiguous bytes per half-wave: byte prefix inside the lane's chunk, half-wave scan of the chunk totals, running
+// carry from step to step.
+__device__ __forceinline__ void delta_decode_page(const PageJob& job, bool do_delta, uint32_t sl)
+{
+    if (!wave::any(do_delta)) return;
+    wave::global_fence();                       // the page's own stores first
+    for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
+        uint32_t lo = 0, hi = 0;
+        if (do_delta && ((job.dc->color_mask >> c) & 1u)) {
+            const uint32_t cs = job.dc->sub_stream_off[c], ce = job.dc->sub_stream_off[c + 1];
+            const uint32_t ps = job.page_off, pe = job.page_off + job.out_size;
+            if (cs < pe && ps < ce) { lo = (cs > ps ? cs : ps) - ps; hi = (ce < pe ? ce : pe) - ps; }
+        }
+        uint32_t carry = 0;
+        for (uint32_t base = lo & ~15u; wave::any(base < hi); base += 512u) {
+            const uint32_t pos = base + sl * 16u;
+            const bool full = pos >= lo && pos + 16u <= hi;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (full) {
+                __builtin_memcpy(w, __builtin_assume_aligned(job.out + pos, 16), 16);
+            } else {
+                for (uint32_t i = 0; i < 16u; ++i)
+                    if (pos + i >= lo && pos + i < hi) w[i >> 2] |= (uint32_t)job.out[pos + i] << (8u * (i & 3u));
+            }
+            w[0] = byte_prefix(w[0]);
+            w[1] = byte_add(byte_prefix(w[1]), w[0] >> 24);
+            w[2] = byte_add(byte_prefix(w[2]), w[1] >> 24);
+            w[3] = byte_add(byte_prefix(w[3]), w[2] >> 24);
+            const uint32_t total = w[3] >> 24;
+            const uint32_t incl = wave::half_scan_incl(total) & 0xFFu;
+            const uint32_t add = (carry + incl - total) & 0xFFu;
+            for (uint32_t k = 0; k < 4u; ++k) w[k] = byte_add(w[k], add);
+            if (full) {
+                __builtin_memcpy(__builtin_assume_aligned(job.out + pos, 16), w, 16);
+            } else {
+                for (uint32_t i = 0; i < 16u; ++i)
+                    if (pos + i >= lo && pos + i < hi) job.out[pos + i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
+            }
+            carry = (carry + wave::half_shfl(incl, 31u)) & 0xFFu;
+        }
+    }
+}
+
+// ---- stage: sources of copies that lie below the output window ("far": in global memory, flushed by an earlier group).
+// The first far_len bytes of a piece's pattern are far.  A piece that lies below the window as a whole, does not overlap
+// itself and is at most kShortCopy bytes long (far_len == plen) never touches the staging area: its own lane fetches it
+// and its bytes go from registers straight to their place in the window (`direct`).  Pieces of 8 bytes and more are
+// covered by 8-byte chunks at offsets 0, 8, 16, 24 clipped to plen - 8 (the last chunk ends exactly at the piece's end
+// and overlaps its predecessor); shorter ones by one load and a split store.  Everything else that reaches below the
+// window is staged (8-byte aligned slots of the staging area, offsets by a half-wave scan): longer pieces, and patterns
+// that straddle the window boundary.  Staged pieces of up to kShortCopy bytes are fetched by their own lane too; as soon
+// as one is longer, all staged pieces get teams of lanes (two chunks per lane at once, the rest at store time).
+// fetch_far_sources issues the loads and returns without waiting; store_far_sources puts the bytes where they belong.
+struct FarSources {
+    uint64_t fe0, fe1, fe2, fe3;    // own-lane chunks
+    uint64_t te0, te1;              // team chunks
+    Team     team;
+    uint32_t t_src, t_len, t_stage; // the team's piece: page position of its source, far bytes, staging offset
+    uint32_t stage_off;             // this lane's piece: 8-byte aligned offset into the staging area
+    bool     direct, staged, any_staged, teams;
+};
+__device__ __forceinline__ FarSources fetch_far_sources(const uint8_t* out, uint32_t plen, uint32_t psrc, uint32_t far_len, uint32_t sl)
+{
+    FarSources f;
+    f.direct = far_len != 0u && far_len == plen && plen <= kShortCopy;
+    f.staged = far_len != 0u && !f.direct;
+    const uint32_t stage_len = f.staged ? (far_len + 7u) & ~7u : 0u;
+    f.any_staged = wave::any(f.staged);
+    f.stage_off = 0;
+    if (f.any_staged) f.stage_off = wave::half_scan_incl(stage_len) - stage_len;
+    f.teams = f.any_staged && wave::any(f.staged && far_len > kShortCopy);
+    f.fe0 = f.fe1 = f.fe2 = f.fe3 = f.te0 = f.te1 = 0;
+    f.team = Team{5u, 0u, 0u, false};
+    f.t_src = f.t_len = f.t_stage = 0;
+    const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
+    if (far_len != 0u && (f.direct || !f.teams)) {
+        const uint8_t* s8 = out + psrc;
+        const uint32_t lim = f.direct ? clip8 : 24u;            // a staged piece keeps plain offsets
+        f.fe0 = load_u64u(s8);
+        if (far_len > 8u) f.fe1 = load_u64u(s8 + min_u32(8u, lim));
+        if (far_len > 16u) f.fe2 = load_u64u(s8 + min_u32(16u, lim));
+        if (far_len > 24u) f.fe3 = load_u64u(s8 + min_u32(24u, lim));
+    }
+    if (f.teams) {
+        const uint32_t staged_mask = wave::half_ballot(f.staged);
+        f.team = make_team(staged_mask, sl);
+        f.t_src = wave::half_shfl(psrc, f.team.job); f.t_len = wave::half_shfl(far_len, f.team.job);
+        f.t_stage = wave::half_shfl(f.stage_off, f.team.job);
+        f.team.serves = f.team.serves && staged_mask != 0u;
+        const uint32_t tsz = 1u << f.team.log2_size;
+        if (f.team.serves && 8u * f.team.member < f.t_len) f.te0 = load_u64u(out + f.t_src + 8u * f.team.member);
+        if (f.team.serves && 8u * (f.team.member + tsz) < f.t_len) f.te1 = load_u64u(out + f.t_src + 8u * (f.team.member + tsz));
+    }
+    return f;
+}
+__device__ __forceinline__ void store_far_sources(uint8_t* win, uint64_t* stage, const uint8_t* out, const FarSources& f, uint32_t plen, uint32_t far_len, uint32_t dst_idx)
+{
+    const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
+    if (f.direct) {
+        uint8_t* d = win + dst_idx;
+        if (plen >= 8u) {
+            __builtin_memcpy(d, &f.fe0, 8);
+            if (plen > 8u) __builtin_memcpy(d + min_u32(8u, clip8), &f.fe1, 8);
+            if (plen > 16u) __builtin_memcpy(d + min_u32(16u, clip8), &f.fe2, 8);
+            if (plen > 24u) __builtin_memcpy(d + clip8, &f.fe3, 8);
+        } else store_bytes(d, f.fe0, plen);
+    }
+    if (f.any_staged) {
+        if (!f.teams) {
+            if (f.staged) {
+                uint64_t* st = &stage[f.stage_off >> 3];
+                st[0] = f.fe0;
+                if (far_len > 8u) st[1] = f.fe1;
+                if (far_len > 16u) st[2] = f.fe2;
+                if (far_len > 24u) st[3] = f.fe3;
+            }
+        } else {
+            const uint32_t tsz = 1u << f.team.log2_size;
+            if (f.team.serves && 8u * f.team.member < f.t_len) stage[(f.t_stage >> 3) + f.team.member] = f.te0;
+            if (f.team.serves && 8u * (f.team.member + tsz) < f.t_len) stage[(f.t_stage >> 3) + f.team.member + tsz] = f.te1;
+            for (uint32_t c = f.team.member + 2u * tsz; wave::any(f.team.serves && 8u * c < f.t_len); c += tsz) {
+                if (f.team.serves && 8u * c < f.t_len) stage[(f.t_stage >> 3) + c] = load_u64u(out + f.t_src + 8u * c);
+            }
+        }
+    }
+}
+
+// ---- stage: which earlier pieces of the group does my copy read?  The pieces of a group are consecutive commands (every
+// command has at least one byte), each starting at byte `first_rel` of the group: a bitmap of the starts (bit p <=> a
+// piece starts at group byte p) and the number of starts before each of its words answer "which piece owns byte x" with
+// one popcount.  Returns the lanes (of the half) whose pieces own bytes of [psrc, src_end) inside the group and come
+// before me; everything below the group (page position gpos) is final.
+template <class Clock>
+__device__ __forceinline__ uint32_t piece_dependencies(uint32_t* start_bits, uint8_t* start_cum, bool on, bool in_group, uint32_t first_rel, uint32_t gpos,
+                                                        uint32_t psrc, uint32_t src_end, bool has_piece, uint32_t sl, Clock& clk)
+{
+    const uint32_t piece_mask = wave::half_ballot(in_group);
+    if (on && sl < kRoundMax / 32u) start_bits[sl] = 0u;
+    wave::sync();
+    if (in_group) atomicOr(&start_bits[first_rel >> 5], 1u << (first_rel & 31u));
+    wave::sync();
+    {
+        const bool rd = on && sl < kRoundMax / 32u;
+        const uint32_t w = rd ? start_bits[sl] : 0u;
+        const uint32_t cw = wave::half_scan_incl((uint32_t)__popc(w));
+        if (rd) start_cum[sl] = (uint8_t)(cw - (uint32_t)__popc(w));
+    }
+    wave::sync();
+    clk.lap(kPhBitmaps);
+    uint32_t m = 0;
+    if (has_piece && src_end > gpos) {
+        const uint32_t first_piece = ctz_u32(piece_mask);
+        const uint32_t hi_rel = src_end - 1u - gpos;
+        const uint32_t hi = start_cum[hi_rel >> 5] + (uint32_t)__popc(start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
+        uint32_t lo = 0;
+        if (psrc > gpos) {
+            const uint32_t lo_rel = psrc - gpos;
+            lo = start_cum[lo_rel >> 5] + (uint32_t)__popc(start_bits[lo_rel >> 5] & (0xFFFFFFFFu >> (31u - (lo_rel & 31u)))) - 1u;
+        }
+        // ranks lo .. hi-1 among the group's pieces: rank r is lane first_piece + r; only pieces before me can be unfinished
+        const uint32_t lo_l = first_piece + lo, hi_l = min_u32(first_piece + hi, sl);
+        if (hi_l > lo_l) m = ((1u << hi_l) - 1u) & ~((1u << lo_l) - 1u);
+    }
+    return m;
+}
+
 // ===========================================================================================
 // Stages of a page decode shared by the fused kernel (decode_pages) and the entropy kernel of the
 // split experiment (brotlig_split_kernels.h).  `Lds` is the per-half LDS record: both kinds carry
@@ -852,8 +1193,8 @@ __device__ __forceinline__ uint8_t* build_lens(PageLds& L, uint32_t) { return L.
 // the sub-stream size table (:79-121), start their bit readers and build the three prefix-code tables (:125-147).
 // `on_pull(job)` is called by every lane of a half for every page the half takes.  Returns whether this half starts a
 // page; `tables_ok` = all three descriptions were defined.
-template <class Lds, class OnPull, class Clock>
-__device__ __forceinline__ bool start_pages(const DecodeArgs& a, Lds& L, PageJob& job, BitReader& br, bool want, bool& finished,
+template <class Lds, class Reader, class OnPull, class Clock>
+__device__ __forceinline__ bool start_pages(const DecodeArgs& a, Lds& L, PageJob& job, Reader& br, bool want, bool& finished,
                                             uint32_t sl, uint16_t* far_syms, bool& tables_ok, OnPull on_pull, Clock& clk)
 {
     const uint32_t total = a.page_base[a.num_streams];
@@ -929,9 +1270,9 @@ struct RoundCommands {
 // One command per lane.  Two refill points per command: with >= 32 bits in the window the command symbol (<= 15 bits)
 // leaves >= 17 for the insert/copy extra bits, and likewise the distance symbol for its extra bits; longer fields
 // (rare) take the general read.
-template <class Lds, class Clock>
+template <class Lds, class Reader, class Clock>
 __device__ __forceinline__ RoundCommands decode_round_commands(const Lds& L, const uint32_t* len_code_tab, const TableRef& t_icp, const TableRef& t_dist,
-                                                                BitReader& br, bool live, uint32_t sl, Clock& clk)
+                                                                Reader& br, bool live, uint32_t sl, Clock& clk)
 {
     RoundCommands c;
     uint32_t sym = 0, len = 0;
@@ -1184,38 +1525,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             const uint32_t g0 = g * kRoundMax, g1 = on ? min_u32(round_bytes, g0 + kRoundMax) : g0;
             const uint32_t gpos = out_pos + g0;                         // page position of the group's first byte
 
-            // -- 3b. flush, and make room in the window when the group does not fit.  Every group first stores the
-            //        finished bytes below it (aligned 16-byte pieces; `flushed` is 16-byte aligned until the page's
-            //        last flush and at most kRoundMax + 15 bytes behind), so that a far copy -- source below the
-            //        window, i.e. more than kHist >= kRoundMax + 16 bytes back -- only ever reads global memory
-            //        written by an EARLIER group's flush.  The slide keeps kHist .. kHist + 15 bytes of history and
-            //        brings them down in one step, all reads before the writes.
-            const bool slide = on && out_pos + g1 > view.win_base + kWin && !(kAblate & kAblSlide);
-            wave::sync();
-            {
-                const uint32_t e16 = gpos & ~15u;
-                const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
-                const bool f0 = on && p0 < e16, f1 = on && p1 < e16;
-                Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0;
-                if (f0) a0 = load16(view.win + (p0 - view.win_base));
-                if (f1) a1 = load16(view.win + (p1 - view.win_base));
-                if (f0) store16(job.out + p0, a0);
-                if (f1) store16(job.out + p1, a1);
-                if (on && e16 > flushed) flushed = e16;
-            }
-            if (wave::any(slide)) {
-                const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
-                const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
-                const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
-                Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0;
-                if (i0 < count) m0 = load16(view.win + shift + i0);
-                if (i1 < count) m1 = load16(view.win + shift + i1);
-                wave::sync();
-                if (i0 < count) store16(view.win + i0, m0);
-                if (i1 < count) store16(view.win + i1, m1);
-                view.win_base = nb;
-            }
-            wave::sync();
+            // -- 3b. flush the finished bytes, slide the window when the group does not fit
+            flush_and_slide(view, flushed, job.out, on, gpos, out_pos + g1, sl);
             clk.lap(kPhSlide);
             clk.count(kPhGroups, 1);
             clk.halves(kPhGroupHalves, on);
@@ -1244,97 +1555,18 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             // Everything else that reaches below the window is staged: longer pieces, and patterns that straddle
             // the window boundary.  Staged pieces of up to kShortCopy bytes are fetched by their own lane too; as
             // soon as one is longer, all staged pieces get teams of lanes (two chunks per lane now, the rest later).
-            const bool far_direct = far_len != 0u && far_len == plen && plen <= kShortCopy;
-            const bool staged = far_len != 0u && !far_direct;
-            const uint32_t stage_len = staged ? (far_len + 7u) & ~7u : 0u;
-            const bool any_staged = wave::any(staged);
-            uint32_t stage_off = 0;                                     // 8-byte aligned offset into L.stage
-            if (any_staged) stage_off = wave::half_scan_incl(stage_len) - stage_len;
-            const bool far_teams = any_staged && wave::any(staged && far_len > kShortCopy);
-            uint64_t fe0 = 0, fe1 = 0, fe2 = 0, fe3 = 0, te0 = 0, te1 = 0;
-            Team ft{5u, 0u, 0u, false};
-            uint32_t ft_src = 0, ft_len = 0, ft_stage = 0;
-            const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
-            if (far_len != 0u && (far_direct || !far_teams)) {
-                const uint8_t* s8 = job.out + psrc;
-                const uint32_t lim = far_direct ? clip8 : 24u;          // a staged piece keeps plain offsets
-                fe0 = load_u64u(s8);
-                if (far_len > 8u) fe1 = load_u64u(s8 + min_u32(8u, lim));
-                if (far_len > 16u) fe2 = load_u64u(s8 + min_u32(16u, lim));
-                if (far_len > 24u) fe3 = load_u64u(s8 + min_u32(24u, lim));
-            }
-            if (far_teams) {
-                const uint32_t staged_mask = wave::half_ballot(staged);
-                ft = make_team(staged_mask, sl);
-                ft_src = wave::half_shfl(psrc, ft.job); ft_len = wave::half_shfl(far_len, ft.job);
-                ft_stage = wave::half_shfl(stage_off, ft.job);
-                ft.serves = ft.serves && staged_mask != 0u;
-                if (ft.serves && 8u * ft.member < ft_len) te0 = load_u64u(job.out + ft_src + 8u * ft.member);
-                if (ft.serves && 8u * (ft.member + (1u << ft.log2_size)) < ft_len) te1 = load_u64u(job.out + ft_src + 8u * (ft.member + (1u << ft.log2_size)));
-            }
+            const FarSources far = fetch_far_sources(job.out, plen, psrc, far_len, sl);
+            const bool far_direct = far.direct;
+            const uint32_t stage_off = far.stage_off;
             clk.lap(kPhPieces);
             // literals of the group: consumption indices [F0, F1)
             const uint32_t mine_before = (on && ok_cmd) ? (cs <= g0 ? ins : (rel0 < g0 ? g0 - rel0 : 0u)) : 0u;   // my literals before g0
             uint32_t F0 = 0, F1 = litcount;                             // single group: all of the round's literals
             if (multi_group) { F0 = wave::half_sum(mine_before); F1 = F0 + wave::half_sum(nlit); }
-            const uint32_t piece_mask = wave::half_ballot(in_group);
-            if (on && sl < kRoundMax / 32u) L.start_bits[sl] = 0u;
-            wave::sync();
-            if (in_group) {
-                const uint32_t b = (rel0 > g0 ? rel0 : g0) - g0;        // my first byte in the group
-                atomicOr(&L.start_bits[b >> 5], 1u << (b & 31u));
-            }
-            wave::sync();
-            {
-                const bool rd = on && sl < kRoundMax / 32u;
-                const uint32_t w = rd ? L.start_bits[sl] : 0u;
-                const uint32_t cw = wave::half_scan_incl((uint32_t)__popc(w));
-                if (rd) L.start_cum[sl] = (uint8_t)(cw - (uint32_t)__popc(w));
-            }
-            wave::sync();
-            clk.lap(kPhBitmaps);
-            // exact dependencies of a source range [s0, s1) of mine: the pieces (of commands before me) that own bytes
-            // of it inside this group; everything below the group is final
-            const uint32_t first_piece = ctz_u32(piece_mask);
-            auto deps_of = [&](uint32_t s0, uint32_t s1) -> uint32_t {
-                uint32_t m = 0;
-                if (s1 > gpos) {
-                    const uint32_t hi_rel = s1 - 1u - gpos;
-                    const uint32_t hi = L.start_cum[hi_rel >> 5] + (uint32_t)__popc(L.start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
-                    uint32_t lo = 0;
-                    if (s0 > gpos) {
-                        const uint32_t lo_rel = s0 - gpos;
-                        lo = L.start_cum[lo_rel >> 5] + (uint32_t)__popc(L.start_bits[lo_rel >> 5] & (0xFFFFFFFFu >> (31u - (lo_rel & 31u)))) - 1u;
-                    }
-                    // ranks lo .. hi-1 among the group's pieces; the pieces are consecutive commands (every
-                    // command has at least one byte), so rank r is lane first_piece + r.  Only pieces before
-                    // me can still be unfinished.
-                    const uint32_t lo_l = first_piece + lo, hi_l = min_u32(first_piece + hi, sl);
-                    if (hi_l > lo_l) m = ((1u << hi_l) - 1u) & ~((1u << lo_l) - 1u);
-                }
-                return m;
-            };
-            uint32_t dep_mask = (plen && !(kAblate & kAblDeps)) ? deps_of(psrc, src_end) : 0u;
-            // Forwarding: a piece that does not overlap itself and whose whole source lies inside ONE earlier piece of
-            // the same kind (a plain copy inside the window) reads that piece's source instead of its output -- the
-            // same bytes, one dependency level earlier (chains of copies of copies are a fifth of all levels on mixed
-            // data, two fifths on records).  Its dependencies are then those of the new range.
-            uint32_t fsrc = psrc;
-            if (kForwardHops != 0u && !(kAblate & kAblDeps)) {
-                const bool plain = plen != 0u && dist >= plen && far_len == 0u;
-                const uint32_t plain_mask = wave::half_ballot(plain);
-#pragma nounroll
-                for (uint32_t hop = 0; hop < kForwardHops; ++hop) {
-                    const bool single = plain && dep_mask != 0u && (dep_mask & (dep_mask - 1u)) == 0u && ((plain_mask & dep_mask) != 0u);
-                    if (!wave::any(single)) break;
-                    const uint32_t d = single ? ctz_u32(dep_mask) : 0u;
-                    const uint32_t d_dst = wave::half_shfl(pdst, d), d_len = wave::half_shfl(plen, d), d_src = wave::half_shfl(fsrc, d);
-                    if (single && fsrc >= d_dst && fsrc + plen <= d_dst + d_len) {
-                        fsrc = d_src + (fsrc - d_dst);
-                        dep_mask = deps_of(fsrc, fsrc + plen);
-                    }
-                }
-            }
+            // exact dependencies of my copy piece: the pieces (of commands before me) that own bytes of its source range
+            // inside this group; everything below the group is final
+            const uint32_t dep_mask = piece_dependencies(L.start_bits, L.start_cum, on, in_group, (rel0 > g0 ? rel0 : g0) - g0, gpos,
+                                                         psrc, src_end, plen != 0u && !(kAblate & kAblDeps), sl, clk);
             clk.lap(kPhCopyFence);
 
             // -- 4. literals of the group.  Literal j of the round comes from sub-stream j mod 32 and is
@@ -1400,170 +1632,14 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
 
             // -- 5a. far sources: short whole pieces straight into the window, everything else into the
             //        staging area (aligned 8-byte LDS writes)
-            const uint32_t src_idx = fsrc - view.win_base;              // window index of the pattern start (negative when far)
+            const uint32_t src_idx = psrc - view.win_base;              // window index of the pattern start (negative when far)
             const uint32_t dst_idx = pdst - view.win_base;
-            if (far_direct) {
-                uint8_t* d = L.win + dst_idx;
-                if (plen >= 8u) {
-                    __builtin_memcpy(d, &fe0, 8);
-                    if (plen > 8u) __builtin_memcpy(d + min_u32(8u, clip8), &fe1, 8);
-                    if (plen > 16u) __builtin_memcpy(d + min_u32(16u, clip8), &fe2, 8);
-                    if (plen > 24u) __builtin_memcpy(d + clip8, &fe3, 8);
-                } else store_bytes(d, fe0, plen);
-            }
-            if (any_staged) {
-                if (!far_teams) {
-                    if (staged) {
-                        uint64_t* st = &L.stage[stage_off >> 3];
-                        st[0] = fe0;
-                        if (far_len > 8u) st[1] = fe1;
-                        if (far_len > 16u) st[2] = fe2;
-                        if (far_len > 24u) st[3] = fe3;
-                    }
-                } else {
-                    const uint32_t tsz = 1u << ft.log2_size;
-                    if (ft.serves && 8u * ft.member < ft_len) L.stage[(ft_stage >> 3) + ft.member] = te0;
-                    if (ft.serves && 8u * (ft.member + tsz) < ft_len) L.stage[(ft_stage >> 3) + ft.member + tsz] = te1;
-                    for (uint32_t c = ft.member + 2u * tsz; wave::any(ft.serves && 8u * c < ft_len); c += tsz) {
-                        if (ft.serves && 8u * c < ft_len) L.stage[(ft_stage >> 3) + c] = load_u64u(job.out + ft_src + 8u * c);
-                    }
-                }
-            }
+            store_far_sources(L.win, L.stage, job.out, far, plen, far_len, dst_idx);
             wave::sync();
             clk.lap(kPhLvLong);
 
-            // -- 5b. LZ77 copies in dependency levels.  A piece runs as soon as none of the pieces its
-            //        source overlaps is still unfinished (dep_mask).  A level without long pieces runs one lane
-            //        per piece; otherwise the ready pieces share the 32 lanes as teams, 8 bytes per lane per step.
-            //        Overlapping copies replay their pattern modulo the distance, so a copy never waits for itself.
-            {
-                const uint32_t packed = plen | (far_len << 11) | ((stage_off >> 3) << 22);
-                // simple piece: pattern in one place (window or staging area) and no chunk of a 32-byte batch reads
-                // what an earlier chunk of the batch wrote
-                const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
-                uint32_t todo = wave::half_ballot(plen != 0u && !far_direct && !(kAblate & kAblLevels));
-                while (wave::any(todo != 0u)) {
-                    clk.count(kPhLevels, 1);
-                    clk.halves(kPhLevelHalves, todo != 0u);
-                    const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
-                    const uint32_t ready_mask = wave::half_ballot(ready);
-                    if ((kAblate & kAblTeams) || !wave::any(ready && (plen > (simple ? kOwnCopy : kShortCopy) || ((kAblate & kExpNoB) && !simple)))) {
-                        // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
-                        // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
-                        // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
-                        // wrote, and every byte loaded belongs to the source (a piece ready in this level never
-                        // has another ready piece inside its source).
-                        const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(L.stage) + stage_off : L.win + (int32_t)src_idx;
-                        uint8_t* dp = L.win + dst_idx;
-                        const bool whole = far_len == 0u || far_len == pattern;
-                        const bool lane_a = ready && simple && !(kAblate & kAblOwnLane);
-                        const bool lane_b = ready && !simple && !(kAblate & (kAblOverlap | kExpNoB));
-                        if (lane_a) {
-                            if (plen >= 8u) {
-                                const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
-                                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
-                                v0 = load_u64u(sp);
-                                if (plen > 8u) v1 = load_u64u(sp + c1);
-                                if (plen > 16u) v2 = load_u64u(sp + c2);
-                                if (plen > 24u) v3 = load_u64u(sp + c3);
-                                __builtin_memcpy(dp, &v0, 8);
-                                if (plen > 8u) __builtin_memcpy(dp + c1, &v1, 8);
-                                if (plen > 16u) __builtin_memcpy(dp + c2, &v2, 8);
-                                if (plen > 24u) __builtin_memcpy(dp + c3, &v3, 8);
-                            } else {
-                                store_bytes(dp, load_u64u(sp), plen);
-                            }
-                        }
-                        for (uint32_t o = 32u; wave::any(lane_a && plen > o); o += 32u) {      // further batches: bytes o .. min(o + 32, plen) - 1
-                            if (lane_a && plen > o) {
-                                const uint32_t c0 = min_u32(o, clip8), c1 = min_u32(o + 8u, clip8), c2 = min_u32(o + 16u, clip8), c3 = min_u32(o + 24u, clip8);
-                                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
-                                v0 = load_u64u(sp + c0);
-                                if (plen > o + 8u) v1 = load_u64u(sp + c1);
-                                if (plen > o + 16u) v2 = load_u64u(sp + c2);
-                                if (plen > o + 24u) v3 = load_u64u(sp + c3);
-                                __builtin_memcpy(dp + c0, &v0, 8);
-                                if (plen > o + 8u) __builtin_memcpy(dp + c1, &v1, 8);
-                                if (plen > o + 16u) __builtin_memcpy(dp + c2, &v2, 8);
-                                if (plen > o + 24u) __builtin_memcpy(dp + c3, &v3, 8);
-                            }
-                        }
-                        clk.lap(kPhLvShort);
-                        if (wave::any(lane_b)) {
-                            // The rest.  Self-overlapping pieces with a distance below 32 are copied forward in
-                            // 8-byte chunks from `dd` bytes back, each chunk reading what its predecessors wrote
-                            // (LDS accesses of a wave execute in order); a distance below 8 first lays down eight
-                            // bytes of its pattern and then continues from the smallest multiple of itself that is
-                            // >= 8 (8 - dd >= -dist: the read never reaches below the pattern).  Patterns that
-                            // straddle the window boundary go byte by byte.
-                            const uint8_t* own_stage = reinterpret_cast<const uint8_t*>(L.stage) + stage_off;
-                            const uint8_t* own_win = L.win + (int32_t)src_idx;
-                            uint32_t dd = dist, o0 = 0u, r = 0u;
-                            if (lane_b && whole && dist < 8u) {
-                                store_bytes(dp, pattern_source8(sp, dist, 0u), plen);
-                                dd = (uint32_t)(0x0E0C0A0809080800ull >> (8u * dist)) & 0xFFu;     // 8, 8, 9, 8, 10, 12, 14 for 1..7
-                                o0 = 8u;
-                            }
-                            for (uint32_t o = o0; wave::any(lane_b && o < plen); o += 8u) {
-                                if (lane_b && o < plen) {
-                                    uint64_t v;
-                                    if (whole) v = load_u64u(dp + o - dd);
-                                    else {
-                                        v = 0;
-                                        uint32_t rr = r;
-                                        for (uint32_t b = 0; b < 8u; ++b) {
-                                            const uint64_t x = rr < far_len ? own_stage[rr] : own_win[rr];
-                                            v |= x << (8u * b);
-                                            rr = rr + 1u == dist ? 0u : rr + 1u;
-                                        }
-                                        r = advance_mod(r, 8u, dist);
-                                    }
-                                    store_bytes(dp + o, v, plen - o);
-                                }
-                            }
-                            clk.lap(kPhLvOverlap);
-                        }
-                    } else {
-                    clk.count(kPhTeamLevels, 1);
-                    const Team t = make_team(ready_mask, sl);
-                    const uint32_t t_pk = wave::half_shfl(packed, t.job), t_dist = wave::half_shfl(dist, t.job);
-                    const uint32_t t_src = wave::half_shfl(src_idx, t.job), t_dst = wave::half_shfl(dst_idx, t.job);
-                    const uint32_t t_len = t_pk & 0x7FFu, t_far = (t_pk >> 11) & 0x7FFu;
-                    const uint8_t* t_stage = reinterpret_cast<const uint8_t*>(L.stage) + ((t_pk >> 22) << 3);
-                    const uint8_t* t_win = L.win + (int32_t)t_src;
-                    uint8_t* t_out = L.win + t_dst;
-                    const bool act = t.serves && ready_mask != 0u;
-                    const uint32_t t_pat = t_dist < t_len ? t_dist : t_len;
-                    const bool whole = t_far == 0u || t_far == t_pat;    // pattern in one place (window or staging area)
-                    const uint8_t* t_base = t_far ? t_stage : t_win;
-                    const bool overlap = t_dist < t_len;
-                    clk.lap(kPhLvShort);
-                    for (uint32_t c = t.member; wave::any(act && 8u * c < t_len); c += 1u << t.log2_size) {
-                        const uint32_t j = 8u * c;
-                        if (act && j < t_len) {
-                            uint32_t r = j;
-                            if (overlap) r = mod_u16(j, t_dist);
-                            uint64_t v;
-                            if (whole) v = pattern_source8(t_base, t_dist, r);
-                            else {                                      // pattern straddles the window boundary: byte by byte
-                                v = 0;
-                                uint32_t rr = r;
-                                for (uint32_t b = 0; b < 8u; ++b) {
-                                    const uint32_t x = rr < t_far ? t_stage[rr] : t_win[rr];
-                                    v |= (uint64_t)x << (8u * b);
-                                    rr = rr + 1u == t_dist ? 0u : rr + 1u;
-                                }
-                            }
-                            store_bytes(t_out + j, v, t_len - j);
-                        }
-                        wave::sync();
-                    }
-                    clk.lap(kPhLvBytes);
-                    }
-                    todo &= ~ready_mask;
-                    wave::sync();
-                }
-            }
+            // -- 5b. LZ77 copies in dependency levels
+            copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
             clk.lap(kPhCopyLevels);
         }
 
@@ -1585,49 +1661,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
         if (ended) flushed = flush_window(job.out, view, flushed, out_pos, true, sl);
         if (ended && out_pos != job.out_size) bad = true;                // a valid page fills its output exactly
 
-    // ---- per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): a running byte
-    //      sum over each colour range inside the page.
-    const bool do_delta = ended && (L.page_params >> 16) != 0u && !bad;
-    if (wave::any(do_delta)) {
-        wave::global_fence();
-        for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
-            uint32_t lo = 0, hi = 0;
-            if (do_delta && ((job.dc->color_mask >> c) & 1u)) {
-                const uint32_t cs = job.dc->sub_stream_off[c], ce = job.dc->sub_stream_off[c + 1];
-                const uint32_t ps = job.page_off, pe = job.page_off + job.out_size;
-                if (cs < pe && ps < ce) { lo = (cs > ps ? cs : ps) - ps; hi = (ce < pe ? ce : pe) - ps; }
-            }
-            // 16 bytes per lane and step, 512 contiguous bytes per half-wave: byte prefix inside the
-            // lane's chunk, half-wave scan of the chunk totals, running carry from step to step.
-            uint32_t carry = 0;
-            for (uint32_t base = lo & ~15u; wave::any(base < hi); base += 512u) {
-                const uint32_t pos = base + sl * 16u;
-                const bool full = pos >= lo && pos + 16u <= hi;
-                uint32_t w[4] = {0u, 0u, 0u, 0u};
-                if (full) {
-                    __builtin_memcpy(w, __builtin_assume_aligned(job.out + pos, 16), 16);
-                } else {
-                    for (uint32_t i = 0; i < 16u; ++i)
-                        if (pos + i >= lo && pos + i < hi) w[i >> 2] |= (uint32_t)job.out[pos + i] << (8u * (i & 3u));
-                }
-                w[0] = byte_prefix(w[0]);
-                w[1] = byte_add(byte_prefix(w[1]), w[0] >> 24);
-                w[2] = byte_add(byte_prefix(w[2]), w[1] >> 24);
-                w[3] = byte_add(byte_prefix(w[3]), w[2] >> 24);
-                const uint32_t total = w[3] >> 24;
-                const uint32_t incl = wave::half_scan_incl(total) & 0xFFu;
-                const uint32_t add = (carry + incl - total) & 0xFFu;
-                for (uint32_t k = 0; k < 4u; ++k) w[k] = byte_add(w[k], add);
-                if (full) {
-                    __builtin_memcpy(__builtin_assume_aligned(job.out + pos, 16), w, 16);
-                } else {
-                    for (uint32_t i = 0; i < 16u; ++i)
-                        if (pos + i >= lo && pos + i < hi) job.out[pos + i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
-                }
-                carry = (carry + wave::half_shfl(incl, 31u)) & 0xFFu;
-            }
-        }
-    }
+    // ---- per-page delta decode of the colour sub-streams
+    delta_decode_page(job, ended && (L.page_params >> 16) != 0u && !bad, sl);
     if (ended && bad && sl == 0u) atomicOr(a.status, kStatusBadPage);
     }
     clk.lap(kPhDelta);

@@ -307,38 +307,8 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
             const uint32_t g0 = g * kRoundMax, g1 = on ? min_u32(round_bytes, g0 + kRoundMax) : g0;
             const uint32_t gpos = out_pos + g0;                         // page position of the group's first byte
 
-            // -- 3b. flush, and make room in the window when the group does not fit.  Every group first stores the
-            //        finished bytes below it (aligned 16-byte pieces; `flushed` is 16-byte aligned until the page's
-            //        last flush and at most kRoundMax + 15 bytes behind), so that a far copy -- source below the
-            //        window, i.e. more than kHist >= kRoundMax + 16 bytes back -- only ever reads global memory
-            //        written by an EARLIER group's flush.  The slide keeps kHist .. kHist + 15 bytes of history and
-            //        brings them down in one step, all reads before the writes.
-            const bool slide = on && out_pos + g1 > view.win_base + kWin && !(kAblate & kAblSlide);
-            wave::sync();
-            {
-                const uint32_t e16 = gpos & ~15u;
-                const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
-                const bool f0 = on && p0 < e16, f1 = on && p1 < e16;
-                Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0;
-                if (f0) a0 = load16(view.win + (p0 - view.win_base));
-                if (f1) a1 = load16(view.win + (p1 - view.win_base));
-                if (f0) store16(job.out + p0, a0);
-                if (f1) store16(job.out + p1, a1);
-                if (on && e16 > flushed) flushed = e16;
-            }
-            if (wave::any(slide)) {
-                const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
-                const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
-                const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
-                Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0;
-                if (i0 < count) m0 = load16(view.win + shift + i0);
-                if (i1 < count) m1 = load16(view.win + shift + i1);
-                wave::sync();
-                if (i0 < count) store16(view.win + i0, m0);
-                if (i1 < count) store16(view.win + i1, m1);
-                view.win_base = nb;
-            }
-            wave::sync();
+            // -- 3b. flush the finished bytes, slide the window when the group does not fit
+            flush_and_slide(view, flushed, job.out, on, gpos, out_pos + g1, sl);
             clk.lap(kPhSlide);
             clk.count(kPhGroups, 1);
             clk.halves(kPhGroupHalves, on);
@@ -366,34 +336,9 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
             // Everything else that reaches below the window is staged: longer pieces, and patterns that straddle
             // the window boundary.  Staged pieces of up to kShortCopy bytes are fetched by their own lane too; as
             // soon as one is longer, all staged pieces get teams of lanes (two chunks per lane now, the rest later).
-            const bool far_direct = far_len != 0u && far_len == plen && plen <= kShortCopy;
-            const bool staged = far_len != 0u && !far_direct;
-            const uint32_t stage_len = staged ? (far_len + 7u) & ~7u : 0u;
-            const bool any_staged = wave::any(staged);
-            uint32_t stage_off = 0;                                     // 8-byte aligned offset into L.stage
-            if (any_staged) stage_off = wave::half_scan_incl(stage_len) - stage_len;
-            const bool far_teams = any_staged && wave::any(staged && far_len > kShortCopy);
-            uint64_t fe0 = 0, fe1 = 0, fe2 = 0, fe3 = 0, te0 = 0, te1 = 0;
-            Team ft{5u, 0u, 0u, false};
-            uint32_t ft_src = 0, ft_len = 0, ft_stage = 0;
-            const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
-            if (far_len != 0u && (far_direct || !far_teams)) {
-                const uint8_t* s8 = job.out + psrc;
-                const uint32_t lim = far_direct ? clip8 : 24u;          // a staged piece keeps plain offsets
-                fe0 = load_u64u(s8);
-                if (far_len > 8u) fe1 = load_u64u(s8 + min_u32(8u, lim));
-                if (far_len > 16u) fe2 = load_u64u(s8 + min_u32(16u, lim));
-                if (far_len > 24u) fe3 = load_u64u(s8 + min_u32(24u, lim));
-            }
-            if (far_teams) {
-                const uint32_t staged_mask = wave::half_ballot(staged);
-                ft = make_team(staged_mask, sl);
-                ft_src = wave::half_shfl(psrc, ft.job); ft_len = wave::half_shfl(far_len, ft.job);
-                ft_stage = wave::half_shfl(stage_off, ft.job);
-                ft.serves = ft.serves && staged_mask != 0u;
-                if (ft.serves && 8u * ft.member < ft_len) te0 = load_u64u(job.out + ft_src + 8u * ft.member);
-                if (ft.serves && 8u * (ft.member + (1u << ft.log2_size)) < ft_len) te1 = load_u64u(job.out + ft_src + 8u * (ft.member + (1u << ft.log2_size)));
-            }
+            const FarSources far = fetch_far_sources(job.out, plen, psrc, far_len, sl);
+            const bool far_direct = far.direct;
+            const uint32_t stage_off = far.stage_off;
             clk.lap(kPhPieces);
             // my literal run in this group: fetched from the page's literal array by my own lane, now; stored to the window
             // once the dependency analysis below has covered the latency.  Runs of 8 bytes and more as 8-byte chunks at
@@ -419,64 +364,8 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
                 if (nlit > 16u) le2 = load_u64u(lsrc + min_u32(16u, lclip));
                 if (nlit > 24u) le3 = load_u64u(lsrc + lclip);
             }
-            const uint32_t piece_mask = wave::half_ballot(in_group);
-            if (on && sl < kRoundMax / 32u) L.start_bits[sl] = 0u;
-            wave::sync();
-            if (in_group) {
-                const uint32_t b = (rel0 > g0 ? rel0 : g0) - g0;        // my first byte in the group
-                atomicOr(&L.start_bits[b >> 5], 1u << (b & 31u));
-            }
-            wave::sync();
-            {
-                const bool rd = on && sl < kRoundMax / 32u;
-                const uint32_t w = rd ? L.start_bits[sl] : 0u;
-                const uint32_t cw = wave::half_scan_incl((uint32_t)__popc(w));
-                if (rd) L.start_cum[sl] = (uint8_t)(cw - (uint32_t)__popc(w));
-            }
-            wave::sync();
-            clk.lap(kPhBitmaps);
-            // exact dependencies of a source range [s0, s1) of mine: the pieces (of commands before me) that own bytes
-            // of it inside this group; everything below the group is final
-            const uint32_t first_piece = ctz_u32(piece_mask);
-            auto deps_of = [&](uint32_t s0, uint32_t s1) -> uint32_t {
-                uint32_t m = 0;
-                if (s1 > gpos) {
-                    const uint32_t hi_rel = s1 - 1u - gpos;
-                    const uint32_t hi = L.start_cum[hi_rel >> 5] + (uint32_t)__popc(L.start_bits[hi_rel >> 5] & (0xFFFFFFFFu >> (31u - (hi_rel & 31u))));
-                    uint32_t lo = 0;
-                    if (s0 > gpos) {
-                        const uint32_t lo_rel = s0 - gpos;
-                        lo = L.start_cum[lo_rel >> 5] + (uint32_t)__popc(L.start_bits[lo_rel >> 5] & (0xFFFFFFFFu >> (31u - (lo_rel & 31u)))) - 1u;
-                    }
-                    // ranks lo .. hi-1 among the group's pieces; the pieces are consecutive commands (every
-                    // command has at least one byte), so rank r is lane first_piece + r.  Only pieces before
-                    // me can still be unfinished.
-                    const uint32_t lo_l = first_piece + lo, hi_l = min_u32(first_piece + hi, sl);
-                    if (hi_l > lo_l) m = ((1u << hi_l) - 1u) & ~((1u << lo_l) - 1u);
-                }
-                return m;
-            };
-            uint32_t dep_mask = (plen && !(kAblate & kAblDeps)) ? deps_of(psrc, src_end) : 0u;
-            // Forwarding: a piece that does not overlap itself and whose whole source lies inside ONE earlier piece of
-            // the same kind (a plain copy inside the window) reads that piece's source instead of its output -- the
-            // same bytes, one dependency level earlier (chains of copies of copies are a fifth of all levels on mixed
-            // data, two fifths on records).  Its dependencies are then those of the new range.
-            uint32_t fsrc = psrc;
-            if (kForwardHops != 0u && !(kAblate & kAblDeps)) {
-                const bool plain = plen != 0u && dist >= plen && far_len == 0u;
-                const uint32_t plain_mask = wave::half_ballot(plain);
-#pragma nounroll
-                for (uint32_t hop = 0; hop < kForwardHops; ++hop) {
-                    const bool single = plain && dep_mask != 0u && (dep_mask & (dep_mask - 1u)) == 0u && ((plain_mask & dep_mask) != 0u);
-                    if (!wave::any(single)) break;
-                    const uint32_t d = single ? ctz_u32(dep_mask) : 0u;
-                    const uint32_t d_dst = wave::half_shfl(pdst, d), d_len = wave::half_shfl(plen, d), d_src = wave::half_shfl(fsrc, d);
-                    if (single && fsrc >= d_dst && fsrc + plen <= d_dst + d_len) {
-                        fsrc = d_src + (fsrc - d_dst);
-                        dep_mask = deps_of(fsrc, fsrc + plen);
-                    }
-                }
-            }
+            const uint32_t dep_mask = piece_dependencies(L.start_bits, L.start_cum, on, in_group, (rel0 > g0 ? rel0 : g0) - g0, gpos,
+                                                         psrc, src_end, plen != 0u && !(kAblate & kAblDeps), sl, clk);
             clk.lap(kPhCopyFence);
 
             // -- 4. literal runs to their place in the window (PageDecoder.cpp:209-211)
@@ -507,170 +396,14 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
 
             // -- 5a. far sources: short whole pieces straight into the window, everything else into the
             //        staging area (aligned 8-byte LDS writes)
-            const uint32_t src_idx = fsrc - view.win_base;              // window index of the pattern start (negative when far)
+            const uint32_t src_idx = psrc - view.win_base;              // window index of the pattern start (negative when far)
             const uint32_t dst_idx = pdst - view.win_base;
-            if (far_direct) {
-                uint8_t* d = L.win + dst_idx;
-                if (plen >= 8u) {
-                    __builtin_memcpy(d, &fe0, 8);
-                    if (plen > 8u) __builtin_memcpy(d + min_u32(8u, clip8), &fe1, 8);
-                    if (plen > 16u) __builtin_memcpy(d + min_u32(16u, clip8), &fe2, 8);
-                    if (plen > 24u) __builtin_memcpy(d + clip8, &fe3, 8);
-                } else store_bytes(d, fe0, plen);
-            }
-            if (any_staged) {
-                if (!far_teams) {
-                    if (staged) {
-                        uint64_t* st = &L.stage[stage_off >> 3];
-                        st[0] = fe0;
-                        if (far_len > 8u) st[1] = fe1;
-                        if (far_len > 16u) st[2] = fe2;
-                        if (far_len > 24u) st[3] = fe3;
-                    }
-                } else {
-                    const uint32_t tsz = 1u << ft.log2_size;
-                    if (ft.serves && 8u * ft.member < ft_len) L.stage[(ft_stage >> 3) + ft.member] = te0;
-                    if (ft.serves && 8u * (ft.member + tsz) < ft_len) L.stage[(ft_stage >> 3) + ft.member + tsz] = te1;
-                    for (uint32_t c = ft.member + 2u * tsz; wave::any(ft.serves && 8u * c < ft_len); c += tsz) {
-                        if (ft.serves && 8u * c < ft_len) L.stage[(ft_stage >> 3) + c] = load_u64u(job.out + ft_src + 8u * c);
-                    }
-                }
-            }
+            store_far_sources(L.win, L.stage, job.out, far, plen, far_len, dst_idx);
             wave::sync();
             clk.lap(kPhLvLong);
 
-            // -- 5b. LZ77 copies in dependency levels.  A piece runs as soon as none of the pieces its
-            //        source overlaps is still unfinished (dep_mask).  A level without long pieces runs one lane
-            //        per piece; otherwise the ready pieces share the 32 lanes as teams, 8 bytes per lane per step.
-            //        Overlapping copies replay their pattern modulo the distance, so a copy never waits for itself.
-            {
-                const uint32_t packed = plen | (far_len << 11) | ((stage_off >> 3) << 22);
-                // simple piece: pattern in one place (window or staging area) and no chunk of a 32-byte batch reads
-                // what an earlier chunk of the batch wrote
-                const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
-                uint32_t todo = wave::half_ballot(plen != 0u && !far_direct && !(kAblate & kAblLevels));
-                while (wave::any(todo != 0u)) {
-                    clk.count(kPhLevels, 1);
-                    clk.halves(kPhLevelHalves, todo != 0u);
-                    const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
-                    const uint32_t ready_mask = wave::half_ballot(ready);
-                    if ((kAblate & kAblTeams) || !wave::any(ready && (plen > (simple ? kOwnCopy : kShortCopy) || ((kAblate & kExpNoB) && !simple)))) {
-                        // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
-                        // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
-                        // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
-                        // wrote, and every byte loaded belongs to the source (a piece ready in this level never
-                        // has another ready piece inside its source).
-                        const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(L.stage) + stage_off : L.win + (int32_t)src_idx;
-                        uint8_t* dp = L.win + dst_idx;
-                        const bool whole = far_len == 0u || far_len == pattern;
-                        const bool lane_a = ready && simple && !(kAblate & kAblOwnLane);
-                        const bool lane_b = ready && !simple && !(kAblate & (kAblOverlap | kExpNoB));
-                        if (lane_a) {
-                            if (plen >= 8u) {
-                                const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
-                                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
-                                v0 = load_u64u(sp);
-                                if (plen > 8u) v1 = load_u64u(sp + c1);
-                                if (plen > 16u) v2 = load_u64u(sp + c2);
-                                if (plen > 24u) v3 = load_u64u(sp + c3);
-                                __builtin_memcpy(dp, &v0, 8);
-                                if (plen > 8u) __builtin_memcpy(dp + c1, &v1, 8);
-                                if (plen > 16u) __builtin_memcpy(dp + c2, &v2, 8);
-                                if (plen > 24u) __builtin_memcpy(dp + c3, &v3, 8);
-                            } else {
-                                store_bytes(dp, load_u64u(sp), plen);
-                            }
-                        }
-                        for (uint32_t o = 32u; wave::any(lane_a && plen > o); o += 32u) {      // further batches: bytes o .. min(o + 32, plen) - 1
-                            if (lane_a && plen > o) {
-                                const uint32_t c0 = min_u32(o, clip8), c1 = min_u32(o + 8u, clip8), c2 = min_u32(o + 16u, clip8), c3 = min_u32(o + 24u, clip8);
-                                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
-                                v0 = load_u64u(sp + c0);
-                                if (plen > o + 8u) v1 = load_u64u(sp + c1);
-                                if (plen > o + 16u) v2 = load_u64u(sp + c2);
-                                if (plen > o + 24u) v3 = load_u64u(sp + c3);
-                                __builtin_memcpy(dp + c0, &v0, 8);
-                                if (plen > o + 8u) __builtin_memcpy(dp + c1, &v1, 8);
-                                if (plen > o + 16u) __builtin_memcpy(dp + c2, &v2, 8);
-                                if (plen > o + 24u) __builtin_memcpy(dp + c3, &v3, 8);
-                            }
-                        }
-                        clk.lap(kPhLvShort);
-                        if (wave::any(lane_b)) {
-                            // The rest.  Self-overlapping pieces with a distance below 32 are copied forward in
-                            // 8-byte chunks from `dd` bytes back, each chunk reading what its predecessors wrote
-                            // (LDS accesses of a wave execute in order); a distance below 8 first lays down eight
-                            // bytes of its pattern and then continues from the smallest multiple of itself that is
-                            // >= 8 (8 - dd >= -dist: the read never reaches below the pattern).  Patterns that
-                            // straddle the window boundary go byte by byte.
-                            const uint8_t* own_stage = reinterpret_cast<const uint8_t*>(L.stage) + stage_off;
-                            const uint8_t* own_win = L.win + (int32_t)src_idx;
-                            uint32_t dd = dist, o0 = 0u, r = 0u;
-                            if (lane_b && whole && dist < 8u) {
-                                store_bytes(dp, pattern_source8(sp, dist, 0u), plen);
-                                dd = (uint32_t)(0x0E0C0A0809080800ull >> (8u * dist)) & 0xFFu;     // 8, 8, 9, 8, 10, 12, 14 for 1..7
-                                o0 = 8u;
-                            }
-                            for (uint32_t o = o0; wave::any(lane_b && o < plen); o += 8u) {
-                                if (lane_b && o < plen) {
-                                    uint64_t v;
-                                    if (whole) v = load_u64u(dp + o - dd);
-                                    else {
-                                        v = 0;
-                                        uint32_t rr = r;
-                                        for (uint32_t b = 0; b < 8u; ++b) {
-                                            const uint64_t x = rr < far_len ? own_stage[rr] : own_win[rr];
-                                            v |= x << (8u * b);
-                                            rr = rr + 1u == dist ? 0u : rr + 1u;
-                                        }
-                                        r = advance_mod(r, 8u, dist);
-                                    }
-                                    store_bytes(dp + o, v, plen - o);
-                                }
-                            }
-                            clk.lap(kPhLvOverlap);
-                        }
-                    } else {
-                    clk.count(kPhTeamLevels, 1);
-                    const Team t = make_team(ready_mask, sl);
-                    const uint32_t t_pk = wave::half_shfl(packed, t.job), t_dist = wave::half_shfl(dist, t.job);
-                    const uint32_t t_src = wave::half_shfl(src_idx, t.job), t_dst = wave::half_shfl(dst_idx, t.job);
-                    const uint32_t t_len = t_pk & 0x7FFu, t_far = (t_pk >> 11) & 0x7FFu;
-                    const uint8_t* t_stage = reinterpret_cast<const uint8_t*>(L.stage) + ((t_pk >> 22) << 3);
-                    const uint8_t* t_win = L.win + (int32_t)t_src;
-                    uint8_t* t_out = L.win + t_dst;
-                    const bool act = t.serves && ready_mask != 0u;
-                    const uint32_t t_pat = t_dist < t_len ? t_dist : t_len;
-                    const bool whole = t_far == 0u || t_far == t_pat;    // pattern in one place (window or staging area)
-                    const uint8_t* t_base = t_far ? t_stage : t_win;
-                    const bool overlap = t_dist < t_len;
-                    clk.lap(kPhLvShort);
-                    for (uint32_t c = t.member; wave::any(act && 8u * c < t_len); c += 1u << t.log2_size) {
-                        const uint32_t j = 8u * c;
-                        if (act && j < t_len) {
-                            uint32_t r = j;
-                            if (overlap) r = mod_u16(j, t_dist);
-                            uint64_t v;
-                            if (whole) v = pattern_source8(t_base, t_dist, r);
-                            else {                                      // pattern straddles the window boundary: byte by byte
-                                v = 0;
-                                uint32_t rr = r;
-                                for (uint32_t b = 0; b < 8u; ++b) {
-                                    const uint32_t x = rr < t_far ? t_stage[rr] : t_win[rr];
-                                    v |= (uint64_t)x << (8u * b);
-                                    rr = rr + 1u == t_dist ? 0u : rr + 1u;
-                                }
-                            }
-                            store_bytes(t_out + j, v, t_len - j);
-                        }
-                        wave::sync();
-                    }
-                    clk.lap(kPhLvBytes);
-                    }
-                    todo &= ~ready_mask;
-                    wave::sync();
-                }
-            }
+            // -- 5b. LZ77 copies in dependency levels
+            copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
             clk.lap(kPhCopyLevels);
         }
 
@@ -689,46 +422,7 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
         wave::sync();
         if (ended) flushed = flush_window(job.out, view, flushed, out_pos, true, sl);
 
-        // per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471), as in the fused kernel
-        const bool do_delta = ended && is_delta != 0u;
-        if (wave::any(do_delta)) {
-            wave::global_fence();
-            for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
-                uint32_t lo = 0, hi = 0;
-                if (do_delta && ((job.dc->color_mask >> c) & 1u)) {
-                    const uint32_t cs = job.dc->sub_stream_off[c], ce = job.dc->sub_stream_off[c + 1];
-                    const uint32_t ps = job.page_off, pe = job.page_off + job.out_size;
-                    if (cs < pe && ps < ce) { lo = (cs > ps ? cs : ps) - ps; hi = (ce < pe ? ce : pe) - ps; }
-                }
-                uint32_t carry = 0;
-                for (uint32_t base = lo & ~15u; wave::any(base < hi); base += 512u) {
-                    const uint32_t pos = base + sl * 16u;
-                    const bool full = pos >= lo && pos + 16u <= hi;
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
-                    if (full) {
-                        __builtin_memcpy(w, __builtin_assume_aligned(job.out + pos, 16), 16);
-                    } else {
-                        for (uint32_t i = 0; i < 16u; ++i)
-                            if (pos + i >= lo && pos + i < hi) w[i >> 2] |= (uint32_t)job.out[pos + i] << (8u * (i & 3u));
-                    }
-                    w[0] = byte_prefix(w[0]);
-                    w[1] = byte_add(byte_prefix(w[1]), w[0] >> 24);
-                    w[2] = byte_add(byte_prefix(w[2]), w[1] >> 24);
-                    w[3] = byte_add(byte_prefix(w[3]), w[2] >> 24);
-                    const uint32_t total = w[3] >> 24;
-                    const uint32_t incl = wave::half_scan_incl(total) & 0xFFu;
-                    const uint32_t add = (carry + incl - total) & 0xFFu;
-                    for (uint32_t k = 0; k < 4u; ++k) w[k] = byte_add(w[k], add);
-                    if (full) {
-                        __builtin_memcpy(__builtin_assume_aligned(job.out + pos, 16), w, 16);
-                    } else {
-                        for (uint32_t i = 0; i < 16u; ++i)
-                            if (pos + i >= lo && pos + i < hi) job.out[pos + i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
-                    }
-                    carry = (carry + wave::half_shfl(incl, 31u)) & 0xFFu;
-                }
-            }
-        }
+        delta_decode_page(job, ended && is_delta != 0u, sl);       // colour sub-streams (PageDecoder.cpp:446-471)
     }
 }
 
@@ -912,47 +606,8 @@ __device__ inline void assemble_pages_global(GlobalAsmLds& L, const DecodeArgs& 
             }
         }
 
-        // per-page delta decode of the colour sub-streams (PageDecoder.cpp:446-471): lanes 0..31, as in the fused kernel
-        if ((flags & kSlotDelta) != 0u) {
-            wave::global_fence();
-            const uint32_t sl = lane & 31u;
-            const bool lower = lane < 32u;
-            for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
-                uint32_t lo = 0, hi = 0;
-                if ((job.dc->color_mask >> c) & 1u) {
-                    const uint32_t cs = job.dc->sub_stream_off[c], ce = job.dc->sub_stream_off[c + 1];
-                    const uint32_t ps = job.page_off, pe = job.page_off + job.out_size;
-                    if (cs < pe && ps < ce) { lo = (cs > ps ? cs : ps) - ps; hi = (ce < pe ? ce : pe) - ps; }
-                }
-                uint32_t carry = 0;
-                for (uint32_t base = lo & ~15u; base < hi; base += 512u) {
-                    const uint32_t pos = base + sl * 16u;
-                    const bool full = lower && pos >= lo && pos + 16u <= hi;
-                    uint32_t w[4] = {0u, 0u, 0u, 0u};
-                    if (full) {
-                        __builtin_memcpy(w, __builtin_assume_aligned(out + pos, 16), 16);
-                    } else if (lower) {
-                        for (uint32_t i = 0; i < 16u; ++i)
-                            if (pos + i >= lo && pos + i < hi) w[i >> 2] |= (uint32_t)out[pos + i] << (8u * (i & 3u));
-                    }
-                    w[0] = byte_prefix(w[0]);
-                    w[1] = byte_add(byte_prefix(w[1]), w[0] >> 24);
-                    w[2] = byte_add(byte_prefix(w[2]), w[1] >> 24);
-                    w[3] = byte_add(byte_prefix(w[3]), w[2] >> 24);
-                    const uint32_t tot = w[3] >> 24;
-                    const uint32_t incl = wave::half_scan_incl(tot) & 0xFFu;
-                    const uint32_t add = (carry + incl - tot) & 0xFFu;
-                    for (uint32_t k = 0; k < 4u; ++k) w[k] = byte_add(w[k], add);
-                    if (full) {
-                        __builtin_memcpy(__builtin_assume_aligned(out + pos, 16), w, 16);
-                    } else if (lower) {
-                        for (uint32_t i = 0; i < 16u; ++i)
-                            if (pos + i >= lo && pos + i < hi) out[pos + i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
-                    }
-                    carry = (carry + wave::half_shfl(incl, 31u)) & 0xFFu;
-                }
-            }
-        }
+        // per-page delta decode (PageDecoder.cpp:446-471): the stage works per half-wave; this page is the lower half's
+        delta_decode_page(job, (flags & kSlotDelta) != 0u && lane < 32u, lane & 31u);
     }
 }
 

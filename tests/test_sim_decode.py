@@ -39,12 +39,6 @@ def sim():
 
 
 @pytest.fixture(scope="module")
-def sim_forwarding():
-    """The kernel source with source forwarding switched on (off in the product: measured neutral), two hops."""
-    return build_sim("libbrotlig_sim_forward.so", ["-DBROTLIG_FORWARD_HOPS=2"])
-
-
-@pytest.fixture(scope="module")
 def sim_small_caps():
     """The same kernel source with room for 24 ICP and 9 distance symbols in LDS: every page sends the rest of its
     symbols through the global-memory overflow."""
@@ -202,19 +196,6 @@ def test_sim_small_caps_every_page_overflows(sim_small_caps):
     tex = tex_thunk()
     outs, status = run_batch(sim_small_caps, [E.encode(tex, precondition=pre)], [len(tex)], precon=True)
     assert status == 0 and np.array_equal(outs[0], tex)
-
-
-def test_sim_source_forwarding_variant(sim_forwarding):
-    """Copies of copies read the first copy's source (kForwardHops > 0): same output."""
-    picks = [c for c in plain_cases() if c[0] in ("text", "mixed", "records", "records_npostfix2", "long_matches", "period_1_2_3", "runs", "mixed_optimal_parse")]
-    streams, sizes, refs = [], [], []
-    for name, thunk, kw in picks + raw_stress_cases()[:2]:
-        data = thunk()
-        streams.append(E.encode(data, **kw)); sizes.append(len(data)); refs.append(data)
-    outs, status = run_batch(sim_forwarding, streams, sizes)
-    assert status == 0
-    for o, r in zip(outs, refs):
-        assert np.array_equal(o, r)
 
 
 def test_sim_simple_code_with_one_symbol_rejects_the_page(sim):
