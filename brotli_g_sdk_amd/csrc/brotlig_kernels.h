@@ -387,6 +387,43 @@ __device__ __forceinline__ uint32_t mod_u16(uint32_t j, uint32_t d)
     if ((uint32_t)rem >= d) rem -= (int32_t)d;
     return (uint32_t)rem;
 }
+// Up to 32 bytes of a piece as 8-byte chunks at offsets 0, 8, 16, 24 clipped to len - 8 (len >= 8): the last chunk ends at the
+// piece's end and overlaps its predecessor, so there are no tail cases -- and a chunk beyond the piece's length, clipped onto
+// the last one, is harmless (same bytes to the same place).  BROTLIG_TUNE_CHUNKS says how many of the four are issued without
+// asking whether the piece is that long: each question is an exec-mask branch, each unconditional chunk an LDS access.
+#ifndef BROTLIG_TUNE_CHUNKS
+#define BROTLIG_TUNE_CHUNKS 2     // measured (round 3, 4 GiB): 0 / 1 / 2 -> mixed 434 / 442 / 444, text 439 / 451 / 449, records 449 / 468 / 473 GB/s
+#endif
+struct Chunks32 { uint64_t v0, v1, v2, v3; };
+#ifndef BROTLIG_TUNE_LIT_CHUNKS
+#define BROTLIG_TUNE_LIT_CHUNKS BROTLIG_TUNE_CHUNKS
+#endif
+template <int kUncond = BROTLIG_TUNE_CHUNKS>
+__device__ __forceinline__ Chunks32 load_chunks32(const uint8_t* sp, uint32_t len, uint32_t clip8)
+{
+    Chunks32 c{0, 0, 0, 0};
+    const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
+    c.v0 = load_u64u(sp);
+    if (kUncond >= 1 || len > 8u) c.v1 = load_u64u(sp + c1);
+    if (kUncond == 1) { if (len > 16u) { c.v2 = load_u64u(sp + c2); c.v3 = load_u64u(sp + c3); } }
+    else {
+        if (kUncond >= 2 || len > 16u) c.v2 = load_u64u(sp + c2);
+        if (kUncond >= 2 || len > 24u) c.v3 = load_u64u(sp + c3);
+    }
+    return c;
+}
+template <int kUncond = BROTLIG_TUNE_CHUNKS>
+__device__ __forceinline__ void store_chunks32(uint8_t* dp, const Chunks32& c, uint32_t len, uint32_t clip8)
+{
+    const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
+    __builtin_memcpy(dp, &c.v0, 8);
+    if (kUncond >= 1 || len > 8u) __builtin_memcpy(dp + c1, &c.v1, 8);
+    if (kUncond == 1) { if (len > 16u) { __builtin_memcpy(dp + c2, &c.v2, 8); __builtin_memcpy(dp + c3, &c.v3, 8); } }
+    else {
+        if (kUncond >= 2 || len > 16u) __builtin_memcpy(dp + c2, &c.v2, 8);
+        if (kUncond >= 2 || len > 24u) __builtin_memcpy(dp + c3, &c.v3, 8);
+    }
+}
 // Copy of `len` bytes by the lane itself when no chunk of a 32-byte batch reads what an earlier chunk of the batch
 // wrote (no overlap, or distance >= 32): 8-byte chunks at offsets clipped to len - 8 (the last chunk ends at the
 // piece's end and overlaps its predecessor), the loads of a batch before its stores.
@@ -395,16 +432,8 @@ __device__ __forceinline__ void own_copy_simple(const uint8_t* sp, uint8_t* dp, 
     const uint32_t clip8 = len >= 8u ? len - 8u : 0u;
     if (on) {
         if (len >= 8u) {
-            const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
-            uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
-            v0 = load_u64u(sp);
-            if (len > 8u) v1 = load_u64u(sp + c1);
-            if (len > 16u) v2 = load_u64u(sp + c2);
-            if (len > 24u) v3 = load_u64u(sp + c3);
-            __builtin_memcpy(dp, &v0, 8);
-            if (len > 8u) __builtin_memcpy(dp + c1, &v1, 8);
-            if (len > 16u) __builtin_memcpy(dp + c2, &v2, 8);
-            if (len > 24u) __builtin_memcpy(dp + c3, &v3, 8);
+            const Chunks32 c = load_chunks32<BROTLIG_TUNE_LIT_CHUNKS>(sp, len, clip8);
+            store_chunks32<BROTLIG_TUNE_LIT_CHUNKS>(dp, c, len, clip8);
         } else {
             store_bytes(dp, load_u64u(sp), len);
         }
@@ -896,16 +925,8 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             const bool lane_b = ready && !simple && !(kAblate & kAblOverlap);
             if (lane_a) {
                 if (plen >= 8u) {
-                    const uint32_t c1 = min_u32(8u, clip8), c2 = min_u32(16u, clip8), c3 = min_u32(24u, clip8);
-                    uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
-                    v0 = load_u64u(sp);
-                    if (plen > 8u) v1 = load_u64u(sp + c1);
-                    if (plen > 16u) v2 = load_u64u(sp + c2);
-                    if (plen > 24u) v3 = load_u64u(sp + c3);
-                    __builtin_memcpy(dp, &v0, 8);
-                    if (plen > 8u) __builtin_memcpy(dp + c1, &v1, 8);
-                    if (plen > 16u) __builtin_memcpy(dp + c2, &v2, 8);
-                    if (plen > 24u) __builtin_memcpy(dp + c3, &v3, 8);
+                    const Chunks32 c = load_chunks32(sp, plen, clip8);
+                    store_chunks32(dp, c, plen, clip8);
                 } else {
                     store_bytes(dp, load_u64u(sp), plen);
                 }
@@ -1078,7 +1099,7 @@ __device__ __forceinline__ FarSources fetch_far_sources(const uint8_t* out, uint
     f.team = Team{5u, 0u, 0u, false};
     f.t_src = f.t_len = f.t_stage = 0;
     const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
-    if (far_len != 0u && (f.direct || !f.teams)) {
+    if (far_len != 0u && (f.direct || !f.teams)) {        // (conditional on purpose: unconditional clipped chunks cost 1.7 % -- more lane-loads on the memory path)
         const uint8_t* s8 = out + psrc;
         const uint32_t lim = f.direct ? clip8 : 24u;            // a staged piece keeps plain offsets
         f.fe0 = load_u64u(s8);
@@ -1103,7 +1124,7 @@ __device__ __forceinline__ void store_far_sources(uint8_t* win, uint64_t* stage,
     const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
     if (f.direct) {
         uint8_t* d = win + dst_idx;
-        if (plen >= 8u) {
+        if (plen >= 8u) {                        // (conditional on purpose: many lanes take part, and a byte-misaligned LDS store costs a cycle per lane)
             __builtin_memcpy(d, &f.fe0, 8);
             if (plen > 8u) __builtin_memcpy(d + min_u32(8u, clip8), &f.fe1, 8);
             if (plen > 16u) __builtin_memcpy(d + min_u32(16u, clip8), &f.fe2, 8);
