@@ -63,7 +63,7 @@ constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
 
 // Launch geometry per device (CU count x occupancy of the decode kernel), looked up once per device;
 // host threads driving different devices (or the same one) may arrive here concurrently.
-struct Grids { int decode = 0, decond = 1024, order = 1024, entropy = 0, assemble = 0, assemble_global = 0; };
+struct Grids { int decode = 0, decond = 1024, order = 1024, entropy = 0, assemble = 0, assemble_global = 0, assemble_page = 0; };
 constexpr int kMaxDevices = 64;
 std::mutex g_grid_mutex;
 Grids g_grids[kMaxDevices];
@@ -105,6 +105,13 @@ BROTLIG_ERROR grid_sizes(Grids* out)
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_entropy_kernel), "BROTLIG_E_PER_CU", &g.entropy)) return e;
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_kernel), "BROTLIG_L_PER_CU", &g.assemble)) return e;
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_global_kernel), "BROTLIG_G_PER_CU", &g.assemble_global)) return e;
+        {   // page-in-LDS assembly: workgroups of kPageWaves wavefronts, 65 KiB of LDS each
+            int n = 0;
+            HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, brotlig_assemble_page_kernel, 64 * (int)kPageWaves, 0));
+            if (const char* e = getenv("BROTLIG_P_PER_CU")) n = atoi(e);
+            if (n < 1) n = 1;
+            g.assemble_page = cus * n;
+        }
 #else
         (void)grid_of;
 #endif
@@ -179,7 +186,8 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
 #ifdef BROTLIG_WITH_SPLIT
     if (a.cmds != nullptr) {                                            // split path: entropy decode, then assembly
         hipLaunchKernelGGL(brotlig_entropy_kernel, dim3(g.entropy), dim3(64), 0, s, a);
-        if (split_mode() == 2) hipLaunchKernelGGL(brotlig_assemble_global_kernel, dim3(g.assemble_global), dim3(64), 0, s, a);
+        if (split_mode() == 3) hipLaunchKernelGGL(brotlig_assemble_page_kernel, dim3(g.assemble_page), dim3(64 * kPageWaves), 0, s, a);
+        else if (split_mode() == 2) hipLaunchKernelGGL(brotlig_assemble_global_kernel, dim3(g.assemble_global), dim3(64), 0, s, a);
         else hipLaunchKernelGGL(brotlig_assemble_kernel, dim3(g.assemble), dim3(64), 0, s, a);
     } else
 #endif

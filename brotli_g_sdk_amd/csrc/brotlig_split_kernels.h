@@ -611,6 +611,165 @@ __device__ inline void assemble_pages_global(GlobalAsmLds& L, const DecodeArgs& 
     }
 }
 
+
+// ---- assembly kernel, third form: the whole page in LDS, one workgroup per page -----------------------------------------------
+// (round 3, last experiment: what would an assembly cost that never reads its own output back from memory?)
+// A workgroup of kPageWaves wavefronts owns one page of at most 64 KiB and keeps all of it in LDS while it is built, so there
+// are no far copies at all: the 30 GB of back-reference line reads of the fused kernel (profiles/r03_traffic_calibration.md) do
+// not exist here, and the output is written once, coalesced.  Two sweeps over the page's command array:
+//   A. literal runs: literal array -> page buffer (independent of everything else);
+//   B. copies, kPageThreads commands per step, one per thread, as DATAFLOW: a copy whose source lies below the step's first
+//      byte runs at once; one that reads bytes of earlier commands of the same step finds those commands by binary search in
+//      the step's position array and polls their done bits (LDS, workgroup scope) -- no barrier between dependency levels,
+//      the wavefronts run ahead as far as their own dependencies allow.  Dependencies point to lower command indices only,
+//      so the lowest unfinished command can always run.
+// 64 KiB + 1.2 KiB of LDS per workgroup: two workgroups per CU.
+#ifndef BROTLIG_PAGE_WAVES
+#define BROTLIG_PAGE_WAVES 4
+#endif
+constexpr uint32_t kPageWaves = BROTLIG_PAGE_WAVES, kPageThreads = 64u * kPageWaves;
+constexpr uint32_t kPageBytes = 65536;
+
+struct __attribute__((aligned(16))) PageAsmLds {
+    uint8_t  page[kPageBytes + 16];
+    uint32_t pos[kPageThreads + 4];         // output position of each of the step's commands, then the step's end
+    uint32_t done[kPageThreads / 32];       // bit t: command t of the step is complete
+    uint32_t ctl[4];                        // [0] the page taken from the work counter
+};
+
+// every command of [lo, hi) of the step complete?
+__device__ __forceinline__ bool page_deps_done(const uint32_t* done, uint32_t lo, uint32_t hi)
+{
+    bool ok = true;
+    for (uint32_t w = lo >> 5; ok && w <= ((hi - 1u) >> 5); ++w) {
+        const uint32_t first = w == (lo >> 5) ? (lo & 31u) : 0u, last = w == ((hi - 1u) >> 5) ? ((hi - 1u) & 31u) : 31u;
+        const uint32_t need = (0xFFFFFFFFu >> (31u - last)) & (0xFFFFFFFFu << first);
+        ok = (wave::lds_load_acquire(done + w) & need) == need;
+    }
+    return ok;
+}
+
+__device__ inline void assemble_pages_in_lds(PageAsmLds& L, const DecodeArgs& a)
+{
+    const uint32_t tid = threadIdx.x, lane = wave::lane_id();
+    const uint32_t total = a.page_base[a.num_streams];
+    const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0u) L.ctl[0] = atomicAdd(a.work_counter2, 1u);
+        __syncthreads();
+        const uint32_t g = L.ctl[0];
+        if (g >= total) break;
+        const PageJob job = fetch_job(a, order, g, true);
+        uint32_t ncmd = 0, flags = 0;
+        if (job.valid) { ncmd = a.slot_hdr[2u * job.index]; flags = a.slot_hdr[2u * job.index + 1u]; }
+        if ((flags & kSlotReady) == 0u || ncmd == 0u) continue;
+        if (job.out_size > kPageBytes) { if (tid == 0u) atomicOr(a.status, kStatusBadPage); continue; }      // (experiment: 64 KiB pages at most)
+        const uint64_t* const cmds = a.cmds + (size_t)job.index * (a.cmd_cap + 1u);
+        const uint8_t* const lits = a.lits + (size_t)job.index * a.lit_stride;
+
+        // ---- A. literal runs (PageDecoder.cpp:209-211).  The words of the next pass are in flight while this one works.
+        {
+            uint64_t pw0 = 0, pw1 = 0;
+            if (tid < ncmd) { pw0 = cmds[tid]; pw1 = cmds[tid + 1u]; }
+            for (uint32_t c0 = 0; c0 < ncmd; c0 += kPageThreads) {
+                const uint64_t w0 = pw0, w1 = pw1;
+                const bool is_cmd = c0 + tid < ncmd;
+                if (c0 + kPageThreads + tid < ncmd) { pw0 = cmds[c0 + kPageThreads + tid]; pw1 = cmds[c0 + kPageThreads + tid + 1u]; }
+                const uint32_t cmd_out = (uint32_t)w0 & 0x3FFFFu, lit_pos = (uint32_t)(w0 >> 18) & 0x3FFFFu;
+                const uint32_t ins = is_cmd ? ((uint32_t)(w1 >> 18) & 0x3FFFFu) - lit_pos : 0u;
+                // runs of up to 64 bytes by their own thread, longer ones by the wavefront of their thread
+                if (ins != 0u && ins <= kCoopLen)
+                    for (uint32_t o = 0; o < ins; o += 8u) store_bytes(L.page + cmd_out + o, load_u64u(lits + lit_pos + o), ins - o);
+                uint64_t lmask = wave::ballot64(ins > kCoopLen);
+                while (lmask != 0ull) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(lmask);
+                    lmask &= lmask - 1ull;
+                    const uint32_t k_dst = wave::uniform(wave::bcast(cmd_out, k)), k_src = wave::uniform(wave::bcast(lit_pos, k));
+                    const uint32_t k_len = wave::uniform(wave::bcast(ins, k));
+                    coop_copy(L.page + k_dst, lits + k_src, k_len, 0xFFFFFFFFu, lane);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- B. copies (PageDecoder.cpp:219-232), one step of kPageThreads commands at a time
+        {
+            uint64_t pw0 = 0, pw1 = 0;
+            if (tid < ncmd) { pw0 = cmds[tid]; pw1 = cmds[tid + 1u]; }
+            for (uint32_t c0 = 0; c0 < ncmd; c0 += kPageThreads) {
+                const uint32_t n = min_u32(kPageThreads, ncmd - c0);
+                const bool is_cmd = tid < n;
+                const uint64_t w0 = pw0, w1 = pw1;
+                if (c0 + kPageThreads + tid < ncmd) { pw0 = cmds[c0 + kPageThreads + tid]; pw1 = cmds[c0 + kPageThreads + tid + 1u]; }
+                const uint32_t cmd_out = (uint32_t)w0 & 0x3FFFFu, lit_pos = (uint32_t)(w0 >> 18) & 0x3FFFFu, dist = (uint32_t)(w0 >> 36) & 0x3FFFFu;
+                const uint32_t next_out = (uint32_t)w1 & 0x3FFFFu, next_lit = (uint32_t)(w1 >> 18) & 0x3FFFFu;
+                const uint32_t ins = is_cmd ? next_lit - lit_pos : 0u;
+                const uint32_t copy = (is_cmd && dist != 0u) ? (next_out - cmd_out) - ins : 0u;
+                const uint32_t cdst = cmd_out + ins, src = cdst - dist;
+                const uint32_t src_end = src + min_u32(copy, dist);
+                if (is_cmd) L.pos[tid] = cmd_out;
+                if (tid == n - 1u) L.pos[n] = next_out;
+                // a command without a copy is complete (its literals are in place): its bit starts set
+                {
+                    const uint64_t nocopy = wave::ballot64(!is_cmd || copy == 0u);
+                    if (lane == 0u) { L.done[2u * (tid >> 6)] = (uint32_t)nocopy; L.done[2u * (tid >> 6) + 1u] = (uint32_t)(nocopy >> 32); }
+                }
+                __syncthreads();
+                const uint32_t S0 = L.pos[0];
+                // the commands of this step (before mine) whose bytes my source touches: [lo, hi)
+                uint32_t lo = 0, hi = 0;
+                if (copy != 0u && src_end > S0) {
+                    const uint32_t xa = src > S0 ? src : S0, xb = src_end - 1u;
+                    uint32_t la = 0, lb = 0;
+                    for (uint32_t step = kPageThreads >> 1; step != 0u; step >>= 1) {
+                        const uint32_t ta = la + step, tb = lb + step;
+                        if (ta < n && L.pos[ta] <= xa) la = ta;
+                        if (tb < n && L.pos[tb] <= xb) lb = tb;
+                    }
+                    lo = la; hi = min_u32(lb + 1u, tid);
+                }
+                bool mine = copy != 0u;
+                const bool simple = dist >= copy, own = copy <= kCoopLen;
+                while (wave::any(mine)) {
+                    const bool ready = mine && (hi <= lo || page_deps_done(L.done, lo, hi));
+                    if (ready && own) {
+                        if (simple) {
+                            const uint32_t clip = copy >= 8u ? copy - 8u : 0u;
+                            if (copy >= 8u) for (uint32_t o = 0; o < copy; o += 8u) { const uint32_t oc = min_u32(o, clip); const uint64_t v = load_u64u(L.page + src + oc); __builtin_memcpy(L.page + cdst + oc, &v, 8); }
+                            else store_bytes(L.page + cdst, load_u64u(L.page + src), copy);
+                        } else {
+                            for (uint32_t o = 0; o < copy; o += 8u) store_bytes(L.page + cdst + o, pattern_source8(L.page + src, dist, mod_u16(o, dist)), copy - o);
+                        }
+                    }
+                    uint64_t big = wave::ballot64(ready && !own);       // long copies: the whole wavefront, one after the other
+                    while (big != 0ull) {
+                        const uint32_t k = (uint32_t)__builtin_ctzll(big);
+                        big &= big - 1ull;
+                        const uint32_t k_dst = wave::uniform(wave::bcast(cdst, k)), k_src = wave::uniform(wave::bcast(src, k));
+                        const uint32_t k_len = wave::uniform(wave::bcast(copy, k)), k_d = wave::uniform(wave::bcast(dist, k));
+                        coop_copy(L.page + k_dst, L.page + k_src, k_len, k_d, lane);
+                    }
+                    const bool progressed = wave::any(ready);
+                    wave::global_fence();                               // the bytes before the bits (workgroup scope)
+                    if (ready) { atomicOr(&L.done[tid >> 5], 1u << (tid & 31u)); mine = false; }
+                    if (!progressed) wave::nap();
+                }
+                __syncthreads();
+            }
+        }
+        // ---- C. the page, once, coalesced: 16 bytes per thread and pass
+        {
+            const uint32_t whole = job.out_size & ~15u;
+            for (uint32_t o = 16u * tid; o < whole; o += 16u * kPageThreads) store16(job.out + o, load16(L.page + o));
+            for (uint32_t o = whole + tid; o < job.out_size; o += kPageThreads) job.out[o] = L.page[o];
+        }
+        // per-page delta decode (PageDecoder.cpp:446-471): in global memory by the first half-wave, as elsewhere (could be done in LDS)
+        __syncthreads();
+        if (tid < 64u) delta_decode_page(job, (flags & kSlotDelta) != 0u && lane < 32u, lane & 31u);
+    }
+}
+
 __global__ void __launch_bounds__(64, BROTLIG_E_WAVES) brotlig_entropy_kernel(DecodeArgs a)
 {
     __shared__ EntropyWaveLds W;
@@ -624,6 +783,12 @@ __global__ void __launch_bounds__(64, BROTLIG_L_WAVES) brotlig_assemble_kernel(D
 {
     __shared__ AssembleWaveLds W;
     assemble_pages(W, a);
+}
+
+__global__ void __launch_bounds__(64 * BROTLIG_PAGE_WAVES) brotlig_assemble_page_kernel(DecodeArgs a)
+{
+    __shared__ PageAsmLds L;
+    assemble_pages_in_lds(L, a);
 }
 
 __global__ void __launch_bounds__(64, BROTLIG_G_WAVES) brotlig_assemble_global_kernel(DecodeArgs a)

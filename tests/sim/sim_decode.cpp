@@ -56,6 +56,7 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
 static void entropy_body(void* p) { brotlig_entropy_kernel(*(DecodeArgs*)p); }
 static void assemble_body(void* p) { brotlig_assemble_kernel(*(DecodeArgs*)p); }
 static void assemble_global_body(void* p) { brotlig_assemble_global_kernel(*(DecodeArgs*)p); }
+static void assemble_page_body(void* p) { brotlig_assemble_page_kernel(*(DecodeArgs*)p); }
 static int g_run_assemble = 0;
 static uint8_t* g_scratch = nullptr;
 extern "C" void sim_set_scratch(uint8_t* p) { g_scratch = p; }
@@ -88,7 +89,8 @@ extern "C" int sim_entropy_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* 
     sim::run_grid(1, prepare_body, &a);
     sim::run_grid(1, policy_body, &a);
     sim::run_grid(decode_grid, entropy_body, &a);
-    if (g_run_assemble) { sim::run_grid(decode_grid, g_run_assemble == 2 ? assemble_global_body : assemble_body, &a); sim::run_grid(3, decond_body, &a); }
+    if (g_run_assemble == 3) { sim::run_grid(decode_grid, assemble_page_body, &a, (int)kPageWaves); sim::run_grid(3, decond_body, &a); }
+    else if (g_run_assemble) { sim::run_grid(decode_grid, g_run_assemble == 2 ? assemble_global_body : assemble_body, &a); sim::run_grid(3, decond_body, &a); }
     *status_out = status_words[0];
     return 0;
 }

@@ -49,7 +49,7 @@ struct WaveState {
     int      index;               // wave number inside the workgroup
 };
 
-constexpr int kMaxWaves = 4;
+constexpr int kMaxWaves = 8;
 extern WaveState g_waves[kMaxWaves];
 extern WaveState* g_cw;           // the wave whose fiber is running
 extern uint64_t g_barrier_gen;    // completed workgroup barriers

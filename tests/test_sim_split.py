@@ -193,3 +193,43 @@ def test_split_path_global_assembly_preconditioned_batch_random(sim):
         data, kw = random_plain(seed)
         outs, status = run_split(sim, [E.encode(data, **kw)], [len(data)], mode=2)
         assert status == 0 and np.array_equal(outs[0], data), seed
+
+
+# ---- the page-in-LDS assembly kernel (one workgroup per page; pages of at most 64 KiB in this experiment) ---------------------
+def _fits_lds(kw):
+    return kw.get("page_size", 65536) <= 65536
+
+
+@pytest.mark.parametrize("name,thunk,kw", [c for c in plain_cases() + raw_stress_cases() + symbol_overflow_cases() if _fits_lds(c[2])],
+                         ids=lambda v: v if isinstance(v, str) else "")
+def test_split_path_page_in_lds_plain(sim, name, thunk, kw):
+    data = np.ascontiguousarray(thunk(), dtype=np.uint8)
+    outs, status = run_split(sim, [E.encode(data, **kw)], [len(data)], mode=3)
+    assert status == 0 and np.array_equal(outs[0], data)
+
+
+def test_split_path_page_in_lds_preconditioned_batch_random(sim):
+    from cases import precon_cases
+    from fuzzcases import random_plain
+    from helpers import oracle_decode
+    for name, thunk, pre in precon_cases():
+        tex = thunk()
+        stream = E.encode(tex, precondition=pre)
+        rc, ref = oracle_decode(stream, out_size=len(tex))
+        assert rc == 0
+        outs, status = run_split(sim, [stream], [len(tex)], precon=True, mode=3)
+        assert status == 0 and np.array_equal(outs[0], ref), name
+    datas = [D.text(65536 + 100, 1), D.runs(3 * 65536, 2), D.random_bytes(65536, 3), D.records(2 * 65536 + 1, 4), D.mixed(65536, 5)]
+    outs, status = run_split(sim, [E.encode(d) for d in datas], [len(d) for d in datas], mode=3)
+    assert status == 0
+    for o, d in zip(outs, datas):
+        assert np.array_equal(o, d)
+    n = 0
+    for seed in range(120):
+        data, kw = random_plain(seed)
+        if not _fits_lds(kw):
+            continue
+        outs, status = run_split(sim, [E.encode(data, **kw)], [len(data)], mode=3)
+        assert status == 0 and np.array_equal(outs[0], data), seed
+        n += 1
+    assert n > 60
