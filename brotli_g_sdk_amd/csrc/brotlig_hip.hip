@@ -447,9 +447,11 @@ void run_shard(BrotligDeviceBatch* b, uint32_t warmup, uint32_t steps, Rendezvou
     b->kernel_ms = 0.0; b->wall_ms = 0.0;
     BROTLIG_ERROR err = BROTLIG_OK;
     hipStream_t s = static_cast<hipStream_t>(b->hip_stream);
-    std::vector<Event> ev(2 * (size_t)steps);
+    std::vector<Event> ev;
     DecodeArgs a{};
     do {
+        try { ev = std::vector<Event>(2 * (size_t)steps); }            // (nothing may leave a thread function: it would terminate the host)
+        catch (...) { err = BROTLIG_ERROR_GENERIC; break; }
         if (!b->d_in || !b->d_out || !b->d_streams || !b->d_workspace || b->num_streams == 0u ||
             b->workspace_bytes < workspace_bytes(b->num_streams)) { err = BROTLIG_ERROR_GENERIC; break; }
         if (hipSetDevice(b->device) != hipSuccess) { err = BROTLIG_ERROR_GENERIC; break; }
