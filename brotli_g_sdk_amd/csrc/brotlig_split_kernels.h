@@ -69,9 +69,88 @@ __device__ __forceinline__ uint8_t* build_lens(EntropyLds& L, uint32_t k)
     return k == 0u ? reinterpret_cast<uint8_t*>(L.lut_lit) : k == 1u ? L.build_tail : L.lit_lens;
 }
 
+
+// ---- the LDS-staged sub-stream ring (`north_star`: "LDS-staged page bitstreams") -------------
+// A/B partner of BitReader for the entropy kernel (-DBROTLIG_E_RING=1): every lane keeps the next 64 bytes of its sub-stream in
+// an LDS ring of four 16-byte blocks, refilled with 16-byte global loads; the bit window takes 32 bits from the ring per refill
+// (one ds_read_b32).  Layout: 8-byte slot s of lane l at ((s * 64 + l) * 8) -- consecutive lanes in consecutive banks.  The
+// block loaded last waits in registers (`flight`) and moves to the ring when two blocks or fewer are ahead of the read
+// position, at which point the next load is issued: like BitReader's queue, a load is never waited for where it is issued.
+// Same interface as BitReader, 4 KiB more LDS per wavefront.
+#ifndef BROTLIG_E_RING
+#define BROTLIG_E_RING 0
+#endif
+struct RingReader {
+    const uint8_t* base;
+    uint32_t limit16;       // last byte offset from base at which 16 bytes may be loaded
+    uint64_t buf;
+    uint32_t avail;
+    uint32_t next;          // byte offset of the next 16-byte load
+    uint32_t rd;            // dwords taken from the ring so far
+    uint32_t wr;            // 16-byte blocks put into the ring so far
+    Bytes16  flight;        // the block loaded last
+    uint32_t* ring;         // LDS, this lane's column: dword d lives at ring[(d >> 1 & 7) * 128 + (d & 1)]
+
+    __device__ __forceinline__ Bytes16 load16g(uint32_t rel) const
+    {
+        Bytes16 v;
+        __builtin_memcpy(&v, base + (rel < limit16 ? rel : limit16), 16);
+        return v;
+    }
+    __device__ __forceinline__ void push(Bytes16 v)
+    {
+        const uint32_t s = (wr & 3u) * 2u;                              // first 8-byte slot of the block
+        const uint64_t lo = (uint64_t)v[0] | ((uint64_t)v[1] << 32), hi = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
+        *reinterpret_cast<uint64_t*>(ring + s * 128u) = lo;
+        *reinterpret_cast<uint64_t*>(ring + (s + 1u) * 128u) = hi;
+        ++wr;
+    }
+    __device__ __forceinline__ void init(const uint8_t* b, uint32_t lim, uint32_t start)
+    {
+        base = b; limit16 = lim >= 16u ? lim - 16u : 0u;
+        const uint32_t a = start & ~3u, skip = (start & 3u) * 8u;
+        rd = 0; wr = 0;
+        push(load16g(a)); push(load16g(a + 16u));
+        flight = load16g(a + 32u); next = a + 48u;
+        buf = 0; avail = 0;
+        refill();
+        buf >>= skip; avail -= skip;
+        if (avail < 32u) refill();
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (wr - (rd >> 2) <= 2u) { push(flight); flight = load16g(next); next += 16u; }
+        const uint32_t w = ring[((rd >> 1) & 7u) * 128u + (rd & 1u)];
+        ++rd;
+        buf |= (uint64_t)w << avail;
+        avail += 32u;
+    }
+    __device__ __forceinline__ void ensure(uint32_t n) { if (avail < n) refill(); }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return n >= 32u ? (uint32_t)buf : ((uint32_t)buf & ((1u << n) - 1u)); }
+    __device__ __forceinline__ void consume(uint32_t n) { buf >>= n; avail -= n; }
+    __device__ __forceinline__ uint32_t read(uint32_t n)
+    {
+        if (n == 0u) return 0u;
+        ensure(n);
+        const uint32_t v = peek(n);
+        consume(n);
+        return v;
+    }
+};
+#if BROTLIG_E_RING
+typedef RingReader EntropyReader;
+#else
+typedef BitReader EntropyReader;
+#endif
+
 struct __attribute__((aligned(16))) EntropyWaveLds {
     EntropyLds page[2];
     uint32_t len_code_tab[48];
+#if BROTLIG_E_RING
+    uint64_t ring[8 * 64];          // sub-stream rings: 64 bytes per lane
+#elif defined(BROTLIG_E_PAD_LDS)
+    uint64_t pad[8 * 64];           // A/B control: the same LDS footprint (hence occupancy) without the ring
+#endif
 };
 
 __device__ inline void entropy_pages(EntropyWaveLds& W, const DecodeArgs& a)
@@ -87,8 +166,16 @@ __device__ inline void entropy_pages(EntropyWaveLds& W, const DecodeArgs& a)
     const uint32_t resync_quarters = a.status[3];
     PageJob job = fetch_job(a, nullptr, 0u, false);
     bool live = false, finished = false, bad = false;
-    BitReader br;
+    EntropyReader br;
+#if BROTLIG_E_RING
+    br.base = a.in; br.limit16 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.rd = 0; br.wr = 4; br.flight = Bytes16{0u, 0u, 0u, 0u};
+    br.ring = reinterpret_cast<uint32_t*>(W.ring) + 2u * lane;
+#else
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
+#ifdef BROTLIG_E_PAD_LDS
+    if (a.num_streams == 0xFFFFFFFFu) W.pad[lane] = 1;                 // (keeps the padding allocated)
+#endif
+#endif
     DistanceRing ring;
     PhaseClock<false> clk;
     uint32_t out_pos = 0;            // bytes of the page accounted for so far
