@@ -1659,8 +1659,13 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             wave::sync();
             clk.lap(kPhLvLong);
 
-            // -- 5b. LZ77 copies in dependency levels
+            // -- 5b. LZ77 copies in dependency levels.  The levels are the longest dependent chain of a round (LDS read -> LDS
+            //        write -> ballot, three to four times over): while a wave is in them it goes first at its SIMD's issue
+            //        port (s_setprio; +1.2 .. 1.5 % measured, any level 1..3; raised around the command decode as well it is
+            //        the same on mixed data and +0.6 % on text, around the whole group loop it loses)
+            wave::set_priority(1);
             copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
+            wave::set_priority(0);
             clk.lap(kPhCopyLevels);
         }
 

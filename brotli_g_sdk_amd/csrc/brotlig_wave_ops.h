@@ -74,6 +74,10 @@ __device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v)
 // Give the SIMD to the other wavefronts for a moment (inside a polling loop).
 __device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(2); }
 
+// Issue priority of this wavefront among the wavefronts of its SIMD (0 = default, anything else = raised): raised around a
+// round's longest dependent chain, so that the wave that is deepest in latency is served first.
+__device__ __forceinline__ void set_priority(int p) { if (p) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+
 // Zero, in a scalar register, that the compiler cannot see through.  Used to turn a register-to-register
 // copy into an ALU operation (x >> opaque_zero()) where a copy would be placed badly -- see BitReader::refill.
 __device__ __forceinline__ uint32_t opaque_zero()

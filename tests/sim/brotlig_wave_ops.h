@@ -27,6 +27,7 @@ inline uint32_t bcast(uint32_t v, uint32_t src, SIM_SITE)
 }
 inline uint32_t uniform(uint32_t v) { return v; }
 inline uint32_t opaque_zero() { return 0u; }
+inline void set_priority(int) {}
 inline uint32_t lds_load_acquire(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 inline void lds_store_release(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 inline void nap() { sim::yield_to_scheduler(); }      // let the other wave of the workgroup run
