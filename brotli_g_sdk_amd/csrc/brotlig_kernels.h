@@ -1380,7 +1380,7 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
     // whose source is already known resolve together; a chain of ring codes takes one pass per link
     // (the lowest unresolved lane is always resolvable).
     uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
-    if (wave::any(pend != 0u)) {           // a round without ring codes 1..15 needs none of this (text: +2 %, mixed even, records -1 %)
+    {
         const uint32_t r = dcode < 4u ? dcode : (dcode < 10u ? 0u : 1u);
         uint32_t below = push_mask & ((1u << sl) - 1u);
         const uint32_t cnt = (uint32_t)__popc(below);
@@ -1405,8 +1405,7 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
     }
     {
         const uint32_t below = push_mask & ((1u << sl) - 1u);
-        uint32_t from = 0;
-        if (wave::any(is_copy && dcode == 0u && below != 0u)) from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
+        const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
         if (is_copy && dcode == 0u) dist = below ? from : ring.r0;
         // the round's last four pushes go to LDS, most recent first; the next round folds them into the ring
         const bool pusher = is_copy && dcode != 0u;
