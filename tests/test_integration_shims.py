@@ -19,10 +19,17 @@ DOC = os.path.join(ROOT, "INTEGRATION.md")
 
 def _doc_block(marker):
     """The fenced code block of INTEGRATION.md whose first line contains `marker`."""
-    text = open(DOC).read()
-    for m in re.finditer(r"```(?:cpp|c)?\n(.*?)```", text, flags=re.S):
-        if marker in m.group(1).split("\n", 1)[0]:
-            return m.group(1)
+    block, inside = None, False
+    for line in open(DOC).read().split("\n"):
+        if line.startswith("```"):
+            if inside:
+                if block and marker in block[0]:
+                    return "\n".join(block) + "\n"
+                inside, block = False, None
+            else:
+                inside, block = True, []
+        elif inside:
+            block.append(line)
     raise AssertionError(f"INTEGRATION.md has no code block starting with {marker!r}")
 
 
@@ -90,3 +97,34 @@ def test_multi_device_example_runs(built):
     r = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit-exact" in r.stdout
+
+
+def test_decode_cpu_feedback_trampoline_of_the_integration_guide_runs(built):
+    """INTEGRATION.md 5b: the reference's C++ DecodeCPU signature (std::string callback) on top of the C twin, through a
+    trampoline.  Compiled from the guide's text and RUN here (CPU only): one progress call per page, abort honoured."""
+    tramp = _doc_block("reference side: DecodeCPU with a working feedbackProc")
+    (built / "cpu_shim.cpp").write_text(
+        '#include <string>\n#include <cstdio>\n#include <cstring>\n#include <vector>\n#include <atomic>\n'
+        '#include "brotlig_amd_cpu.h"\n#include "brotlig_encoder.h"\n'
+        # what the reference's headers provide (inc/common/BrotligCommon.h:70-92), minus what brotlig_amd_cpu.h already declares
+        "typedef bool (*BROTLIG_Feedback_Proc)(BROTLIG_MESSAGE_TYPE type, std::string message);\n"
+        "namespace BrotliG { BROTLIG_ERROR DecodeCPU(uint32_t, const uint8_t*, uint32_t*, uint8_t*, BROTLIG_Feedback_Proc); }\n"
+        + tramp +
+        "static std::atomic<int> calls{0}; static int stop_after = 0;\n"
+        "static bool progress(BROTLIG_MESSAGE_TYPE t, std::string m) { (void)m; return t == BROTLIG_PROGRESS && ++calls >= stop_after && stop_after; }\n"
+        "int main() {\n"
+        "  std::vector<uint8_t> src(5 * 65536 + 123); for (size_t i = 0; i < src.size(); ++i) src[i] = (uint8_t)((i * 2654435761u) >> 13) & 0x3F;\n"
+        "  uint32_t cap = BrotligEncMaxCompressedSize((uint32_t)src.size(), 65536); std::vector<uint8_t> enc(cap);\n"
+        "  BrotligEncodeOptions opt; memset(&opt, 0, sizeof opt);\n"
+        "  if (BrotligEncode((uint32_t)src.size(), src.data(), &cap, enc.data(), &opt) != 0) return 2;\n"
+        "  std::vector<uint8_t> out(src.size()); uint32_t n = (uint32_t)out.size();\n"
+        "  if (BrotliG::DecodeCPU(cap, enc.data(), &n, out.data(), progress) != BROTLIG_OK || n != src.size() || memcmp(out.data(), src.data(), n)) return 3;\n"
+        "  if (calls != 6) return 4;                      // six pages, one message each\n"
+        "  calls = 0; stop_after = 2; n = (uint32_t)out.size();\n"
+        "  if (BrotliG::DecodeCPU(cap, enc.data(), &n, out.data(), progress) != BROTLIG_ABORTED) return 5;\n"
+        "  n = (uint32_t)out.size();\n"
+        "  return BrotliG::DecodeCPU(cap, enc.data(), &n, out.data(), nullptr) == BROTLIG_OK ? 0 : 6;\n}\n")
+    exe = built / "cpu_shim"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC, str(built / "cpu_shim.cpp"), "-o", str(exe),
+                           "-L", CSRC, "-lbrotlig_cpu", "-lbrotlig_enc", "-Wl,-rpath," + CSRC, "-pthread"])
+    subprocess.check_call([str(exe)])
