@@ -33,7 +33,8 @@ def build_encoder(force=False):
 
 def build_cpu(force=False):
     """DecodeCPU of the reference API (inc/BrotligDecoder.h:33): its own library, never loaded by the GPU path."""
-    src = [os.path.join(CSRC, "brotlig_cpu.cpp"), os.path.join(CSRC, "brotlig_format.h"), os.path.join(ROOT, "include", "brotlig_amd.h")]
+    src = [os.path.join(CSRC, "brotlig_cpu.cpp"), os.path.join(CSRC, "brotlig_format.h"), os.path.join(CSRC, "brotlig_shard_plan.h"),
+           os.path.join(ROOT, "include", "brotlig_amd.h"), os.path.join(ROOT, "include", "brotlig_amd_cpu.h")]
     if force or _stale(CPU_SO, src):
         subprocess.check_call(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-I", os.path.join(ROOT, "include"),
                                "-I", CSRC, "-o", CPU_SO, src[0]], cwd=CSRC)
@@ -41,7 +42,7 @@ def build_cpu(force=False):
 
 
 def hip_sources():
-    names = ["brotlig_hip.hip", "brotlig_streamer.hip", "brotlig_kernels.h", "brotlig_split_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h"]
+    names = ["brotlig_hip.hip", "brotlig_streamer.hip", "brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h", "brotlig_shard_plan.h"]
     return [os.path.join(CSRC, n) for n in names] + [os.path.join(ROOT, "include", "brotlig_amd.h")]
 
 

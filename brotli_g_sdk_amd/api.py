@@ -71,6 +71,9 @@ def lib():
         L.BrotligDecodeBatchMultiDevice.restype = ctypes.c_int
         L.BrotligDecodeBatchMultiDevice.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        for name in ("BrotligDecodeBatchMultiDeviceAsync", "BrotligDecodeBatchMultiDeviceWait"):
+            getattr(L, name).restype = ctypes.c_int
+            getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
         L.BrotligContextCreate.restype = ctypes.c_int
         L.BrotligContextCreate.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.BrotligContextDestroy.restype = None
@@ -188,7 +191,7 @@ def DecodeBatchMultiDevice(decoders, warmup=0, steps=1, streams=None):
     arr = (DeviceBatch * n)()
     for i, d in enumerate(decoders):
         b = arr[i]
-        b.device = d.device.index or 0
+        b.device = d.device.index if d.device.index is not None else d.torch.cuda.current_device()
         b.num_streams = d.n
         b.d_in, b.in_bytes = d.d_in.data_ptr(), d.in_bytes
         b.d_out, b.out_bytes = d.d_out.data_ptr(), d.out_bytes

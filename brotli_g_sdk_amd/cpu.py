@@ -23,8 +23,20 @@ def lib():
         L.BrotligDecodeCPUWithFeedback.restype = ctypes.c_int
         L.BrotligDecodeCPUWithFeedback.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p,
                                                    ctypes.c_uint32, FEEDBACK_PROC, ctypes.c_void_p]
+        L.BrotligShardPlan.restype = ctypes.c_int
+        L.BrotligShardPlan.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
         _lib = L
     return _lib
+
+
+def ShardPlan(in_sizes, num_shards):
+    """BrotligShardPlan as exported by libbrotlig_cpu.so (the same code as libbrotlig_hip.so's: csrc/brotlig_shard_plan.h)."""
+    sizes = np.ascontiguousarray(in_sizes, dtype=np.uint64)
+    first = np.zeros(int(num_shards) + 1, dtype=np.uint32)
+    rc = lib().BrotligShardPlan(sizes.ctypes.data, len(sizes), int(num_shards), first.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"BrotligShardPlan failed with {rc}")
+    return [int(x) for x in first]
 
 
 # int (*BrotligFeedbackProc)(int type, const char* message, void* user) -- include/brotlig_amd_cpu.h

@@ -25,6 +25,7 @@ namespace {
 #define __host__
 #define __device__
 #include "brotlig_format.h"
+#include "brotlig_shard_plan.h"
 #undef __host__
 #undef __device__
 using namespace brotlig;
@@ -261,6 +262,7 @@ struct Job {
     std::atomic<uint32_t> next{0}; std::atomic<int> error{0};
     BrotligFeedbackProc feedback = nullptr; void* user = nullptr;           // per-page progress callback (may be null)
     std::atomic<int> aborted{0};
+    uint8_t* done = nullptr;                                                // [num_pages] set by the worker that completed the page
 };
 
 inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
@@ -393,12 +395,20 @@ void worker(Job* J, uint8_t* cond)
         if (off > J->pages_size || size > 0xFFFFFFFFull ||
             !decode_page(P, J->pages + off, (uint32_t)size, J->pages_size - off, dst, out_size, si.page_size, i * si.page_size, J->dc))
             J->error.store(1);
+        else J->done[i] = 1;
         if (J->feedback) {                                                      // src/BrotligDecoder.cpp:318-325
             char msg[48];
             snprintf(msg, sizeof msg, "%f", 100.f * ((float)i / (float)si.num_pages));     // std::to_string(float)
             if (J->feedback(BROTLIG_PROGRESS, msg, J->user)) { J->aborted.store(1); return; }
         }
     }
+}
+// what a pool thread runs: nothing may leave a thread function (it would terminate the host process) -- a bad_alloc of the
+// page context or of its literal queue becomes the job's error
+void pool_worker(Job* J, uint8_t* cond)
+{
+    try { worker(J, cond); }
+    catch (...) { J->error.store(1); }
 }
 
 // conditioned space -> texture, one block at a time (the inverse of PageDecoder.cpp:406-444's address map)
@@ -446,13 +456,21 @@ BROTLIG_ERROR decode_stream(uint32_t input_size, const uint8_t* src, uint32_t* o
         if (!dc.init(rd32(src + 8), rd32(src + 12), *output_size) || usize != *output_size) return BROTLIG_ERROR_GENERIC;
         cond.resize((size_t)si.num_pages * si.page_size);
     }
-    memset(output, 0, *output_size);                                            // :448 -- every stream, like the reference
+    // :448 zeroes all *output_size bytes before anything is decoded.  Same result without the extra pass over the output
+    // (single-threaded, it cost a third of the 32-worker rate: 15.2 -> 10.8 GB/s, profiles/r02_/r03_final_cpu_decode.json):
+    // a plain stream's pages overwrite [0, usize) entirely, so only the tail is zeroed here and, should the decode fail or
+    // be aborted, the pages that were not completed (below); a texture is zeroed as a whole (row-pitch padding stays 0).
+    if (si.preconditioned) memset(output, 0, *output_size);
+    else memset(output + usize, 0, *output_size - usize);
+    std::vector<uint8_t> done(si.num_pages, 0);
     Job J;
+    J.done = done.data();
     J.src = src; J.src_size = input_size; J.table = src + si.header_bytes; J.pages = J.table + 4ull * si.num_pages;
     J.pages_size = input_size - si.header_bytes - 4ull * si.num_pages;
     J.out = output; J.si = si; J.dc = &dc; J.feedback = feedback; J.user = user;
-    // default: one worker per hardware thread up to 32 -- threads are created per call, and on the 256-thread host of
-    // the MI355X box 32 workers decode 15 GB/s where 64 and more fall back to 10 (profiles/r02_cpu_decode.json)
+    // default: one worker per hardware thread up to 32 -- threads are created per call; on the 256-thread host of the
+    // MI355X box 32 workers decoded 15.2 GB/s and 64 and more fell back to 10 (profiles/r02_cpu_decode.json; with round 3's
+    // full up-front memset: 10.8 / 14.4 with 32 / 64, profiles/r03_final_cpu_decode.json)
     uint32_t nw = workers ? workers : std::min(std::thread::hardware_concurrency(), 32u);
     if (nw == 0u) nw = 1u;
     if (nw > si.num_pages) nw = si.num_pages ? si.num_pages : 1u;
@@ -462,15 +480,23 @@ BROTLIG_ERROR decode_stream(uint32_t input_size, const uint8_t* src, uint32_t* o
     // a thread that cannot be created (EAGAIN) is not an error: the workers that did start, and this thread, take
     // the pages from the shared counter
     for (uint32_t t = 1; t < nw; ++t) {
-        try { pool.emplace_back(worker, &J, cond.data()); }
+        try { pool.emplace_back(pool_worker, &J, cond.data()); }
         catch (const std::system_error&) { break; }
     }
     bool threw = false;
     try { worker(&J, cond.data()); }
     catch (...) { J.error.store(1); threw = true; }                             // (bad_alloc of the page context)
     for (auto& t : pool) t.join();
-    if (threw || J.error.load()) return BROTLIG_ERROR_GENERIC;
-    if (J.aborted.load()) return BROTLIG_ABORTED;
+    if (threw || J.error.load() || J.aborted.load()) {
+        // what the reference's up-front memset leaves of a page that was never (or not successfully) decoded: zeros
+        if (!si.preconditioned)
+            for (uint32_t i = 0; i < si.num_pages; ++i)
+                if (!done[i]) {
+                    const uint64_t o = (uint64_t)i * si.page_size;
+                    memset(output + o, 0, (size_t)std::min<uint64_t>(si.page_size, usize - o));
+                }
+        return (threw || J.error.load()) ? BROTLIG_ERROR_GENERIC : BROTLIG_ABORTED;
+    }
     if (si.preconditioned) decondition(dc, cond.data(), output);
     *output_size = (uint32_t)usize;                                             // :490
     return BROTLIG_OK;
@@ -497,6 +523,13 @@ extern "C" BROTLIG_ERROR BrotligDecodeCPUWithFeedback(uint32_t input_size, const
                                                       uint32_t workers, BrotligFeedbackProc feedback, void* user)
 {
     return guarded([&] { return decode_stream(input_size, src, output_size, output, workers, feedback, user); });
+}
+
+// The multi-device shard plan (include/brotlig_amd.h), also exported here: it is host arithmetic, and a host without ROCm
+// (a CPU-only rank, a scheduler) must be able to compute the same cut as the ranks that decode.
+extern "C" BROTLIG_ERROR BrotligShardPlan(const uint64_t* in_sizes, uint32_t num_streams, uint32_t num_shards, uint32_t* first)
+{
+    return guarded([&] { return brotlig::shard_plan(in_sizes, num_streams, num_shards, first) ? BROTLIG_OK : BROTLIG_ERROR_GENERIC; });
 }
 
 // inc/BrotligDecoder.h:32, src/BrotligDecoder.cpp:35-39: no validation.  (libbrotlig_hip.so exports the same

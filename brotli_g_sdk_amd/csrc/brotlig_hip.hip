@@ -19,8 +19,9 @@
 
 #include "brotlig_amd.h"
 #include "brotlig_kernels.h"
+#include "brotlig_shard_plan.h"
 #ifdef BROTLIG_WITH_SPLIT     // experiment builds only (profiles/experiments/r03_split_path.md): not part of the product library
-#include "brotlig_split_kernels.h"
+#include "experimental/brotlig_split_kernels.h"
 #endif
 
 using namespace brotlig;
@@ -39,11 +40,12 @@ static_assert(sizeof(BrotligStreamDesc) == sizeof(StreamDesc), "descriptor layou
 constexpr size_t kWsHeaderWords = 64;
 size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 1023u) & ~(size_t)1023u; }
 // per-half slots for the prefix-code symbols that overflow the LDS arrays, for every workgroup of the largest decode grid
+// (8192 workgroups x 2 halves x kFarSymStride uint16 = 30 MiB: the size brotlig_amd.h documents for the workspace)
 constexpr uint32_t kMaxDecodeGrid = 8192;
 constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
 size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
 size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
-// Split path (brotlig_split_kernels.h): an A/B experiment of round 3, compiled in with -DBROTLIG_WITH_SPLIT only and then
+// Split path (experimental/brotlig_split_kernels.h): an A/B experiment of round 3, compiled in with -DBROTLIG_WITH_SPLIT only and then
 // switched on with BROTLIG_SPLIT=1|2.  Per page one slot of (cap + 1) command words and a literal array of a page plus
 // slack, and two header words.
 #ifdef BROTLIG_WITH_SPLIT
@@ -63,7 +65,17 @@ constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
 
 // Launch geometry per device (CU count x occupancy of the decode kernel), looked up once per device;
 // host threads driving different devices (or the same one) may arrive here concurrently.
-struct Grids { int decode = 0, decond = 1024, order = 1024, entropy = 0, assemble = 0, assemble_global = 0, assemble_page = 0; };
+struct Grids {
+    int decode = 0, decond = 1024, order = 1024;
+#ifdef BROTLIG_WITH_SPLIT
+    int entropy = 0, assemble = 0, assemble_global = 0, assemble_page = 0;
+#endif
+};
+// Diagnostics switches, read ONCE per process (never in the launch path): BROTLIG_WG_PER_CU pins the decode grid per compute unit
+// (profiles/tools/occ_probe.sh), BROTLIG_POLICY the pairing policy (policy_sweep.sh).  -1 = not set.
+int env_int_once(const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; }
+int diag_wg_per_cu() { static const int v = env_int_once("BROTLIG_WG_PER_CU"); return v; }
+int diag_policy() { static const int v = env_int_once("BROTLIG_POLICY"); return v; }
 constexpr int kMaxDevices = 64;
 std::mutex g_grid_mutex;
 Grids g_grids[kMaxDevices];
@@ -84,11 +96,12 @@ BROTLIG_ERROR grid_sizes(Grids* out)
         HIP_OK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(brotlig_decode_kernel)));
         const int granules = (int)((fa.sharedSizeBytes + 1279u) / 1280u);
         if (granules > 0 && per_cu > 128 / granules) per_cu = 128 / granules;
-        if (const char* e = getenv("BROTLIG_WG_PER_CU")) per_cu = atoi(e);      // diagnostics (profiles/tools/occ_probe.sh)
+        if (diag_wg_per_cu() > 0) per_cu = diag_wg_per_cu();
         if (per_cu < 1) per_cu = 1;
         g.decond = cus * 8;
         g.order = cus * 4;
         g.decode = cus * per_cu < (int)kMaxDecodeGrid ? cus * per_cu : (int)kMaxDecodeGrid;
+#ifdef BROTLIG_WITH_SPLIT
         auto grid_of = [&](const void* fn, const char* env, int* out) -> BROTLIG_ERROR {
             int n = 0;
             hipFuncAttributes a{};
@@ -101,7 +114,6 @@ BROTLIG_ERROR grid_sizes(Grids* out)
             *out = cus * n < (int)kMaxDecodeGrid ? cus * n : (int)kMaxDecodeGrid;
             return BROTLIG_OK;
         };
-#ifdef BROTLIG_WITH_SPLIT
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_entropy_kernel), "BROTLIG_E_PER_CU", &g.entropy)) return e;
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_kernel), "BROTLIG_L_PER_CU", &g.assemble)) return e;
         if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_global_kernel), "BROTLIG_G_PER_CU", &g.assemble_global)) return e;
@@ -112,8 +124,6 @@ BROTLIG_ERROR grid_sizes(Grids* out)
             if (n < 1) n = 1;
             g.assemble_page = cus * n;
         }
-#else
-        (void)grid_of;
 #endif
     }
     *out = g;
@@ -151,8 +161,8 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
         a.order_cap = (uint32_t)max_pages(n, out_bytes);
         used = base + 4u * max_pages(n, out_bytes);
     }
-    a.work_counter2 = ws + 4;
 #ifdef BROTLIG_WITH_SPLIT
+    a.work_counter2 = ws + 4;
     if (split_enabled()) {                                              // slots behind the schedule, if the workspace has them
         const uint64_t pages = max_pages(n, out_bytes);
         used = (used + 255u) & ~(size_t)255u;
@@ -165,6 +175,7 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
         }
     }
 #endif
+    (void)used;
     return a;
 }
 
@@ -180,8 +191,8 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
         hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, s, a);
     }
     hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, s, a);
-    if (const char* e = getenv("BROTLIG_POLICY"))       // diagnostics: pin the pairing policy (quarters of a page a free half waits)
-        HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), atoi(e), 1, s));
+    if (diag_policy() >= 0)                             // diagnostics: pin the pairing policy (quarters of a page a free half waits)
+        HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), diag_policy(), 1, s));
     if (k0) HIP_OK(hipEventRecord(k0, s));
 #ifdef BROTLIG_WITH_SPLIT
     if (a.cmds != nullptr) {                                            // split path: entropy decode, then assembly
@@ -285,7 +296,18 @@ struct BrotligContext {
     hipStream_t stream = nullptr;
     Event e0, e1;
     DevBuf in, out, scratch, ws, desc;
+    BrotligStreamDesc* h_desc = nullptr;    // pinned: the descriptor of the call in flight (its upload needs no host-side wait)
     size_t in_cap = 0, out_cap = 0, scratch_cap = 0, ws_cap = 0;
+    BrotligContext() = default;
+    BrotligContext(const BrotligContext&) = delete;
+    BrotligContext& operator=(const BrotligContext&) = delete;
+    // every exit path of every owner releases the stream and the pinned descriptor (the device buffers and events release
+    // themselves); called with the context's device current
+    ~BrotligContext()
+    {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (h_desc) (void)hipHostFree(h_desc);
+    }
 };
 
 namespace {
@@ -322,11 +344,10 @@ BROTLIG_ERROR decode_gpu(BrotligContext& c, uint32_t input_size, const uint8_t* 
     if (si.preconditioned) if (BROTLIG_ERROR e = grow(c.scratch, c.scratch_cap, out_alloc + 64)) return e;
     if (BROTLIG_ERROR e = grow(c.ws, c.ws_cap, ws_size)) return e;
     if (!c.desc.p) HIP_OK(hipMalloc(&c.desc.p, sizeof(BrotligStreamDesc)));
-    const BrotligStreamDesc desc{0, 0, input_size, *output_size};
+    *c.h_desc = BrotligStreamDesc{0, 0, input_size, *output_size};      // pinned and owned by the context: no wait before the launches
     HIP_OK(hipMemsetAsync(static_cast<uint8_t*>(c.in.p) + (in_alloc + 64 - 80), 0, 80, c.stream));
     HIP_OK(hipMemcpyAsync(c.in.p, input, input_size, hipMemcpyHostToDevice, c.stream));
-    HIP_OK(hipMemcpyAsync(c.desc.p, &desc, sizeof desc, hipMemcpyHostToDevice, c.stream));
-    HIP_OK(hipStreamSynchronize(c.stream));                             // `desc` lives on this frame
+    HIP_OK(hipMemcpyAsync(c.desc.p, c.h_desc, sizeof(BrotligStreamDesc), hipMemcpyHostToDevice, c.stream));
     const DecodeArgs a = make_args(c.in.p, input_size, c.out.p, out_alloc, static_cast<BrotligStreamDesc*>(c.desc.p), 1,
                                    c.ws.p, ws_size, si.preconditioned ? c.scratch.p : nullptr);
     BROTLIG_ERROR err = enqueue(a, c.stream, c.e0.e, c.e1.e);
@@ -347,8 +368,16 @@ BROTLIG_ERROR context_init(BrotligContext& c, int device)
     c.device = device;
     HIP_OK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_OK(c.e0.create()); HIP_OK(c.e1.create());
+    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c.h_desc), sizeof(BrotligStreamDesc), hipHostMallocDefault));
     return BROTLIG_OK;
 }
+
+// the calling thread's current device, put back on scope exit
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 }  // namespace
 
@@ -358,7 +387,8 @@ extern "C" BROTLIG_ERROR BrotligContextCreate(int device, BrotligContext** out)
     *out = nullptr;
     BrotligContext* c = new (std::nothrow) BrotligContext;
     if (!c) return BROTLIG_ERROR_GENERIC;
-    if (BROTLIG_ERROR e = context_init(*c, device)) { BrotligContextDestroy(c); return e; }
+    DeviceGuard guard;
+    if (BROTLIG_ERROR e = context_init(*c, device)) { delete c; return e; }
     *out = c;
     return BROTLIG_OK;
 }
@@ -366,8 +396,8 @@ extern "C" BROTLIG_ERROR BrotligContextCreate(int device, BrotligContext** out)
 extern "C" void BrotligContextDestroy(BrotligContext* c)
 {
     if (!c) return;
+    DeviceGuard guard;
     (void)hipSetDevice(c->device);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     delete c;
 }
 
@@ -375,6 +405,7 @@ extern "C" BROTLIG_ERROR BrotligContextDecodeGPU(BrotligContext* c, uint32_t inp
                                                  uint32_t* output_size, uint8_t* output, double* time_ms)
 {
     if (!c) return BROTLIG_ERROR_GENERIC;
+    DeviceGuard guard;                                                  // the caller's current device is restored
     HIP_OK(hipSetDevice(c->device));
     return decode_gpu(*c, input_size, input, output_size, output, time_ms);
 }
@@ -383,45 +414,17 @@ extern "C" BROTLIG_ERROR BrotligContextDecodeGPU(BrotligContext* c, uint32_t inp
 extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, const uint8_t* input,
                                    uint32_t* output_size, uint8_t* output, double* time_ms)
 {
-    BrotligContext c;
+    BrotligContext c;                                                   // (its destructor releases the stream on every path)
     if (BROTLIG_ERROR e = context_init(c, -1)) return e;
-    const BROTLIG_ERROR err = decode_gpu(c, input_size, input, output_size, output, time_ms);
-    if (c.stream) { (void)hipStreamSynchronize(c.stream); (void)hipStreamDestroy(c.stream); }
-    return err;
+    return decode_gpu(c, input_size, input, output_size, output, time_ms);
 }
 
 // ---- multi-device fan-out (SURVEY.md 8(b) row 4 "plus a multi-GPU wrapper", 8(e)) ------------------------------------
-// Streams are independent, so a batch shards with no exchange between devices: contiguous runs of streams, one run per
-// device, cut so that the largest run's COMPRESSED bytes are as small as possible (the cost of a page follows its
-// compressed size, not its 64 KiB of output; 8(e) last row).  Streams are never split (a pre-conditioned stream's pages
-// scatter over its whole texture).  The reference's analogue is the fan-out of pages over host threads,
-// src/BrotligDecoder.cpp:356-375, and of streams over the shader's queue, BrotliGCompute.hlsl:1757-1881.
+// The plan itself is host arithmetic, one definition for every library that exports it: brotlig_shard_plan.h.
 extern "C" BROTLIG_ERROR BrotligShardPlan(const uint64_t* in_sizes, uint32_t num_streams, uint32_t num_shards, uint32_t* first)
 {
-    if (!in_sizes || !first || num_shards == 0u) return BROTLIG_ERROR_GENERIC;
-    // smallest cap such that a left-to-right packing needs at most num_shards runs
-    uint64_t lo = 0, hi = 0;
-    for (uint32_t i = 0; i < num_streams; ++i) { lo = in_sizes[i] > lo ? in_sizes[i] : lo; hi += in_sizes[i]; }
-    auto runs_needed = [&](uint64_t cap) {
-        uint32_t runs = 1; uint64_t acc = 0;
-        for (uint32_t i = 0; i < num_streams; ++i) {
-            if (acc + in_sizes[i] > cap && acc != 0u) { ++runs; acc = 0; }
-            acc += in_sizes[i];
-        }
-        return runs;
-    };
-    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2u; if (runs_needed(mid) <= num_shards) hi = mid; else lo = mid + 1u; }
-    // pack under that cap, but never leave a later shard without a stream while streams remain
-    uint32_t i = 0;
-    for (uint32_t g = 0; g < num_shards; ++g) {
-        first[g] = i;
-        uint64_t acc = 0;
-        const uint32_t shards_after = num_shards - 1u - g;
-        while (i < num_streams && (acc == 0u || acc + in_sizes[i] <= lo) && num_streams - i > shards_after) acc += in_sizes[i++];
-        if (shards_after == 0u) i = num_streams;
-    }
-    first[num_shards] = num_streams;
-    return BROTLIG_OK;
+    try { return shard_plan(in_sizes, num_streams, num_shards, first) ? BROTLIG_OK : BROTLIG_ERROR_GENERIC; }
+    catch (...) { return BROTLIG_ERROR_GENERIC; }
 }
 
 namespace {
@@ -485,8 +488,7 @@ extern "C" BROTLIG_ERROR BrotligDecodeBatchMultiDevice(BrotligDeviceBatch* shard
                                                        uint32_t warmup, uint32_t steps, double* max_kernel_ms, double* max_wall_ms)
 {
     if (!shards || num_shards == 0u || num_shards > 64u || steps == 0u || struct_bytes != sizeof(BrotligDeviceBatch)) return BROTLIG_ERROR_GENERIC;
-    int prev = 0;
-    (void)hipGetDevice(&prev);
+    DeviceGuard guard;                                                  // the calling thread's current device is restored
     try {
         Rendezvous rv(num_shards);
         std::vector<std::thread> pool;
@@ -501,8 +503,7 @@ extern "C" BROTLIG_ERROR BrotligDecodeBatchMultiDevice(BrotligDeviceBatch* shard
         run_shard(shards, warmup, steps, &rv);                          // shard 0 on the calling thread
         for (uint32_t g = started + 1u; g < num_shards; ++g) run_shard(shards + g, warmup, steps, &rv);
         for (auto& t : pool) t.join();
-    } catch (...) { (void)hipSetDevice(prev); return BROTLIG_ERROR_GENERIC; }
-    (void)hipSetDevice(prev);
+    } catch (...) { return BROTLIG_ERROR_GENERIC; }
     BROTLIG_ERROR first_err = BROTLIG_OK;
     double mk = 0.0, mw = 0.0;
     for (uint32_t g = 0; g < num_shards; ++g) {
@@ -512,6 +513,44 @@ extern "C" BROTLIG_ERROR BrotligDecodeBatchMultiDevice(BrotligDeviceBatch* shard
     }
     if (max_kernel_ms) *max_kernel_ms = mk;
     if (max_wall_ms) *max_wall_ms = mw;
+    return first_err;
+}
+
+// Non-blocking form: enqueue every shard on its own device and stream and return; nothing is timed, no host thread is
+// created.  For a caller that already owns its threads / streams (one per device) and overlaps the decode with its own work.
+extern "C" BROTLIG_ERROR BrotligDecodeBatchMultiDeviceAsync(BrotligDeviceBatch* shards, uint32_t num_shards, uint32_t struct_bytes)
+{
+    if (!shards || num_shards == 0u || num_shards > 64u || struct_bytes != sizeof(BrotligDeviceBatch)) return BROTLIG_ERROR_GENERIC;
+    DeviceGuard guard;
+    BROTLIG_ERROR first_err = BROTLIG_OK;
+    for (uint32_t g = 0; g < num_shards; ++g) {
+        BrotligDeviceBatch* b = shards + g;
+        BROTLIG_ERROR err = BROTLIG_OK;
+        b->kernel_ms = 0.0; b->wall_ms = 0.0;
+        if (!b->d_in || !b->d_out || !b->d_streams || !b->d_workspace || b->num_streams == 0u ||
+            b->workspace_bytes < workspace_bytes(b->num_streams) || hipSetDevice(b->device) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
+        else err = enqueue(make_args(b->d_in, b->in_bytes, b->d_out, b->out_bytes, b->d_streams, b->num_streams, b->d_workspace,
+                                     (size_t)b->workspace_bytes, b->d_scratch), static_cast<hipStream_t>(b->hip_stream), nullptr, nullptr);
+        b->result = (int32_t)err;
+        if (err != BROTLIG_OK && first_err == BROTLIG_OK) first_err = err;
+    }
+    return first_err;
+}
+
+// Completes what BrotligDecodeBatchMultiDeviceAsync started: waits for every shard's stream and collects the batch status.
+extern "C" BROTLIG_ERROR BrotligDecodeBatchMultiDeviceWait(BrotligDeviceBatch* shards, uint32_t num_shards, uint32_t struct_bytes)
+{
+    if (!shards || num_shards == 0u || num_shards > 64u || struct_bytes != sizeof(BrotligDeviceBatch)) return BROTLIG_ERROR_GENERIC;
+    DeviceGuard guard;
+    BROTLIG_ERROR first_err = BROTLIG_OK;
+    for (uint32_t g = 0; g < num_shards; ++g) {
+        BrotligDeviceBatch* b = shards + g;
+        if (b->result == BROTLIG_OK) {
+            if (hipSetDevice(b->device) != hipSuccess) b->result = BROTLIG_ERROR_GENERIC;
+            else b->result = (int32_t)BrotligDecodeBatchStatus(b->d_workspace, b->hip_stream);
+        }
+        if (b->result != BROTLIG_OK && first_err == BROTLIG_OK) first_err = (BROTLIG_ERROR)b->result;
+    }
     return first_err;
 }
 

@@ -82,13 +82,15 @@ struct DecodeArgs {
     uint16_t* far_syms;     // [workgroups of the decode grid][2][kFarSymStride] per 32-lane half: the ICP and distance symbols
                             // (canonical-code order) that do not fit the LDS arrays -- ranks kIcpSymCap.. and kDistSymCap..
     unsigned long long* prof;   // [kNumPhases] cycle sums, only written by the phase-timer instantiation
-    // split path (brotlig_split_kernels.h): the entropy kernel leaves every compressed page as a command array and a
+#ifdef BROTLIG_WITH_SPLIT
+    // split path (experimental/brotlig_split_kernels.h): the entropy kernel leaves every compressed page as a command array and a
     // literal array in global memory, the assembly kernel builds the page from them.  Slots are indexed by global page index.
     uint64_t* cmds;             // [pages][cmd_cap + 1] packed commands, then one terminal entry
     uint8_t*  lits;             // [pages][lit_stride] literals in consumption order
     uint32_t* slot_hdr;         // [pages][2]: number of commands, flags (kSlot*)
     uint32_t  cmd_cap, lit_stride;
     uint32_t* work_counter2;    // [1] page counter of the assembly kernel
+#endif
 };
 
 // Phase timers (diagnostics build of the kernel only).
@@ -1192,7 +1194,7 @@ __device__ __forceinline__ uint32_t piece_dependencies(uint32_t* start_bits, uin
 
 // ===========================================================================================
 // Stages of a page decode shared by the fused kernel (decode_pages) and the entropy kernel of the
-// split experiment (brotlig_split_kernels.h).  `Lds` is the per-half LDS record: both kinds carry
+// split experiment (experimental/brotlig_split_kernels.h).  `Lds` is the per-half LDS record: both kinds carry
 // lut_icp / lut_dist / lut_lit, sorted_*, limit, first_offs, page_params and ring_push under
 // these names; where a table's code lengths live while it is built differs (build_lens).
 // All of them run in wave-uniform control flow, with per-half predicates as operands.

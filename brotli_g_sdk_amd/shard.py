@@ -5,14 +5,70 @@ torch.distributed (RCCL on ROCm, gloo in the CPU tests) is used only for the bar
 timing/byte-count reductions of the benchmark."""
 
 
+def shard_plan(in_sizes, num_shards):
+    """Pure-Python twin of BrotligShardPlan (include/brotlig_amd.h, csrc/brotlig_shard_plan.h): the num_shards + 1 run
+    boundaries.  Host arithmetic, so that a rank computes its shard without building or loading any native library (a
+    gloo / CPU-only rank has no hipcc); tests/test_abi.py checks it against the C export of both libraries."""
+    import bisect
+    sizes = [int(x) for x in in_sizes]
+    n, G = len(sizes), int(num_shards)
+    if G <= 0:
+        raise ValueError("num_shards must be positive")
+    pre = [0]
+    for x in sizes:
+        pre.append(pre[-1] + x)
+
+    def run_end(i, cap):            # end of the longest run from i that weighs at most cap (at least one stream)
+        return max(bisect.bisect_right(pre, pre[i] + cap, i + 1) - 1, i + 1)
+
+    def runs_needed(cap):
+        runs, i = 0, 0
+        while i < n:
+            i = run_end(i, cap)
+            runs += 1
+        return runs
+
+    lo, hi = max(sizes, default=0), pre[n]
+    while lo < hi:                  # the bottleneck: smallest cap that packs into at most G runs
+        mid = lo + (hi - lo) // 2
+        if runs_needed(mid) <= G:
+            hi = mid
+        else:
+            lo = mid + 1
+    cap = lo
+    need = [0] * (n + 1)            # runs needed for streams i.. under the cap
+    for i in range(n - 1, -1, -1):
+        need[i] = 1 + need[run_end(i, cap)]
+    first, i = [], 0
+    for g in range(G):
+        first.append(i)
+        after = G - 1 - g
+        if i >= n:
+            continue
+        if after == 0:
+            i = n
+            continue
+        e_max = min(run_end(i, cap), n - min(after, n - i - 1))
+        e_min = i + 1
+        while e_min < e_max and need[e_min] > after:
+            e_min += 1
+        ideal = (pre[n] - pre[i] + (G - g) - 1) // (G - g)      # an even share of what is left
+        best = e_min
+        for e in range(e_min, e_max + 1):
+            if abs(pre[e] - pre[i] - ideal) <= abs(pre[best] - pre[i] - ideal):
+                best = e
+        i = best
+    first.append(n)
+    return first
+
+
 def stream_indices(n_streams, world, rank, in_sizes=None):
     """Contiguous slice of range(n_streams) owned by `rank`: the run BrotligShardPlan (include/brotlig_amd.h) gives it --
     runs balanced by COMPRESSED bytes (`in_sizes`, one per stream; SURVEY.md 8(e): "balance by compressed bytes, not
     page count"), streams never split.  Without sizes every stream weighs the same."""
-    from . import api
     sizes = [1] * n_streams if in_sizes is None else [int(x) for x in in_sizes]
     assert len(sizes) == n_streams
-    first = api.ShardPlan(sizes, world)
+    first = shard_plan(sizes, world)
     return list(range(first[rank], first[rank + 1]))
 
 

@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 /* ABI version of the device-pointer batch interface.  Version 3 (round 3): 32-byte BrotligStreamDesc (was 16), d_in must
- * extend 16 bytes past in_bytes, the workspace holds the per-wavefront symbol slots (+15 MiB).  The entry points whose
+ * extend 16 bytes past in_bytes, the workspace holds the per-wavefront symbol slots (+30 MiB: 8192 workgroups).  The entry points whose
  * contract changed carry the version in their SYMBOL names (the macros below), so a caller built against an older header
  * fails to link instead of passing descriptors of the wrong stride; BrotligAbiVersion() answers at run time (dlopen users). */
 #define BROTLIG_AMD_ABI_VERSION 3
@@ -99,8 +99,8 @@ typedef struct BrotligStreamDesc {
 } BrotligStreamDesc;
 
 /* Bytes of device workspace needed for `num_streams` streams (the reference's `meta` buffer): status words, page
- * counts, pre-conditioning tables, and 15 MiB of per-wavefront slots for prefix-code symbols beyond the kernel's LDS
- * arrays (kept small so that 16 wavefronts fit a compute unit).  One workspace per batch in flight. */
+ * counts, pre-conditioning tables, and 30 MiB of per-wavefront slots (up to 8192 workgroups) for prefix-code symbols beyond
+ * the kernel's LDS arrays (kept small so that 16 wavefronts fit a compute unit).  One workspace per batch in flight. */
 size_t BrotligDecodeWorkspaceSize(uint32_t num_streams);
 /* Workspace size that also holds the page schedule for `out_bytes` of output (one word per page): with
  * it, batches of 768 MiB and more are decoded bucket by bucket, similar pages side by side (about 12 %
@@ -177,6 +177,14 @@ typedef struct BrotligDeviceBatch {
  * Returns the first shard error, BROTLIG_OK if none.  The calling thread's current device is restored. */
 BROTLIG_ERROR BrotligDecodeBatchMultiDevice(BrotligDeviceBatch* shards, uint32_t num_shards, uint32_t struct_bytes,
                                             uint32_t warmup, uint32_t steps, double* max_kernel_ms, double* max_wall_ms);
+
+/* Non-blocking pair for a caller that owns its own threads and streams: ...Async enqueues one BrotligDecodeBatchDevice per
+ * shard on the shard's device and hip_stream and returns at once (no host thread is created, nothing is timed; `result`
+ * holds the enqueue result); ...Wait waits for each shard's stream and stores its batch status in `result`.  Both return
+ * the first shard error and restore the calling thread's current device.  Equivalent by hand: hipSetDevice +
+ * BrotligDecodeBatchDevice per shard, later BrotligDecodeBatchStatus per shard. */
+BROTLIG_ERROR BrotligDecodeBatchMultiDeviceAsync(BrotligDeviceBatch* shards, uint32_t num_shards, uint32_t struct_bytes);
+BROTLIG_ERROR BrotligDecodeBatchMultiDeviceWait(BrotligDeviceBatch* shards, uint32_t num_shards, uint32_t struct_bytes);
 
 /* Device self-test of the wave primitives the kernels rely on (DPP scan vs shuffle scan,
  * half-wave ballot / shuffle / max).  Returns BROTLIG_OK when they agree. */

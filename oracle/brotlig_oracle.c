@@ -385,6 +385,9 @@ static void delta_decode(const DcParams* dc, size_t page_start, size_t page_end,
 }
 
 typedef struct { uint32_t insert_len, copy_len, dist; } Cmd;
+#ifdef BROTLIG_ORACLE_TRACE
+static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_pos, uint32_t litcount, uint32_t rlit);
+#endif
 
 /* PageDecoder.cpp:65-268.  `in` is the SafeBuf of the whole compressed input,
  * the page occupies [in_off, in_off + in_size). */
@@ -501,6 +504,9 @@ static int pd_run(PageDecoder* pd, const SafeBuf* in, size_t in_size, size_t in_
                 ds_switch(&ds);
             }
 
+#ifdef BROTLIG_ORACLE_TRACE      /* diagnostics builds only (profiles/tools/cmd_stats.c): the round's commands, before they are applied */
+            brotlig_oracle_trace_round(queue, n, (uint32_t)(w - dst), litcount, rlit);
+#endif
             for (uint32_t k = 0; k < n; ++k) {                                      /* :209-233 */
                 Cmd c = queue[k];
                 if ((size_t)(lq_back - lq_front) < c.insert_len || (size_t)(w_end - w) < c.insert_len) return -2;

@@ -1,0 +1,130 @@
+/* cmd_stats.c -- diagnostics: what the decode kernel's round loop sees on a .brotlig stream.
+ *
+ * Builds the oracle (oracle/brotlig_oracle.c, test infrastructure) with its trace hook and replays every round through a
+ * model of the fused kernel's bookkeeping (brotlig_kernels.h: 512-byte groups, 1488-byte window with 528 bytes of history,
+ * far / direct / staged pieces, exact piece dependencies -> levels).  Prints one JSON object per stream.
+ *   gcc -O2 -DBROTLIG_ORACLE_TRACE -o build/stats/cmd_stats profiles/tools/cmd_stats.c -lpthread
+ *   build/stats/cmd_stats file.brotlig
+ * Not part of the product or of the tests.
+ */
+#include "../../oracle/brotlig_oracle.c"
+#include <stdio.h>
+
+enum { kWin = 1488, kHist = 528, kRoundMax = 512, kShort = 32, kOwn = 128 };
+static struct {
+    uint64_t rounds, cmds, groups, lit_bytes, copy_bytes, lit_steps;
+    uint64_t pieces_copy, far_direct, far_staged, near_nodep, near_dep, lit_pieces, lit_long;
+    uint64_t levels, level_hist[40], ready_pieces, team_levels, overlap_pieces, short_pieces /* <8 */;
+    uint64_t copy_len_hist[8], ins_hist[8], dist_hist[8];
+    uint64_t multi_group_rounds, slides, ring_like;
+    uint64_t lvl_bytes; /* sum over levels of max piece length in the level */
+    uint64_t levels64; /* levels if 64 consecutive commands were one step */
+} S;
+static __thread uint32_t t_win_base, t_page_out;
+static int bucket(uint32_t v) { return v == 0 ? 0 : v < 2 ? 1 : v < 4 ? 2 : v < 8 ? 3 : v < 16 ? 4 : v < 32 ? 5 : v < 128 ? 6 : 7; }
+static int dbucket(uint32_t d) { return d < 8 ? 0 : d < 32 ? 1 : d < 128 ? 2 : d < 528 ? 3 : d < 2048 ? 4 : d < 8192 ? 5 : d < 32768 ? 6 : 7; }
+
+static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_pos, uint32_t litcount, uint32_t rlit)
+{
+    if (out_pos == 0) t_win_base = 0;
+    uint32_t rel0[33], tot = 0;
+    for (uint32_t k = 0; k < n; ++k) { rel0[k] = tot; tot += q[k].insert_len + q[k].copy_len; }
+    rel0[n] = tot;
+    __sync_fetch_and_add(&S.rounds, 1); __sync_fetch_and_add(&S.cmds, n);
+    __sync_fetch_and_add(&S.lit_bytes, litcount);
+    __sync_fetch_and_add(&S.lit_steps, n ? (rlit / n + 1) / 2 + 0 : 0);
+    for (uint32_t k = 0; k < n; ++k) {
+        __sync_fetch_and_add(&S.ins_hist[bucket(q[k].insert_len)], 1);
+        if (q[k].copy_len) { __sync_fetch_and_add(&S.copy_len_hist[bucket(q[k].copy_len)], 1); __sync_fetch_and_add(&S.dist_hist[dbucket(q[k].dist)], 1);
+                             __sync_fetch_and_add(&S.copy_bytes, q[k].copy_len); }
+    }
+    uint32_t ngroups = (tot + kRoundMax - 1) / kRoundMax;
+    if (ngroups > 1) __sync_fetch_and_add(&S.multi_group_rounds, 1);
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        uint32_t g0 = g * kRoundMax, g1 = tot < g0 + kRoundMax ? tot : g0 + kRoundMax;
+        uint32_t gpos = out_pos + g0, gend = out_pos + g1;
+        if (gend > t_win_base + kWin) { t_win_base = (gpos - kHist) & ~15u; __sync_fetch_and_add(&S.slides, 1); }
+        __sync_fetch_and_add(&S.groups, 1);
+        /* pieces */
+        uint32_t lvl[32], plen[32], first = 32;
+        int any = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            lvl[k] = 0; plen[k] = 0;
+            uint32_t r0 = rel0[k], t = q[k].insert_len + q[k].copy_len, cs = r0 + q[k].insert_len;
+            if (!(r0 < g1 && r0 + t > g0)) continue;
+            if (first == 32) first = k;
+            uint32_t la = r0 > g0 ? r0 : g0, lb = cs < g1 ? cs : g1;
+            if (lb > la) { __sync_fetch_and_add(&S.lit_pieces, 1); if (lb - la > kOwn) __sync_fetch_and_add(&S.lit_long, 1); }
+            uint32_t ca = cs > g0 ? cs : g0, cb = r0 + t < g1 ? r0 + t : g1;
+            if (!q[k].copy_len || cb <= ca) continue;
+            uint32_t pl = cb - ca, pdst = out_pos + ca, psrc = pdst - q[k].dist;
+            uint32_t pattern = pl < q[k].dist ? pl : q[k].dist, src_end = psrc + pattern;
+            uint32_t far_len = psrc < t_win_base ? (pattern < t_win_base - psrc ? pattern : t_win_base - psrc) : 0;
+            __sync_fetch_and_add(&S.pieces_copy, 1);
+            if (pl < 8) __sync_fetch_and_add(&S.short_pieces, 1);
+            if (far_len && far_len == pl && pl <= kShort) { __sync_fetch_and_add(&S.far_direct, 1); continue; }
+            if (far_len) __sync_fetch_and_add(&S.far_staged, 1);
+            plen[k] = pl;
+            if (q[k].dist < pl && q[k].dist < 32) __sync_fetch_and_add(&S.overlap_pieces, 1);
+            /* dependencies: earlier commands of the group owning bytes of [psrc, src_end) */
+            uint32_t l = 1;
+            if (src_end > gpos) {
+                for (uint32_t j = first; j < k; ++j) {
+                    uint32_t a = out_pos + (rel0[j] > g0 ? rel0[j] : g0), b = out_pos + (rel0[j + 1] < g1 ? rel0[j + 1] : g1);
+                    if (a < src_end && b > psrc && lvl[j] + 1 > l) l = lvl[j] + 1;
+                }
+            }
+            lvl[k] = l; any = 1;
+            if (l == 1) __sync_fetch_and_add(far_len ? &S.ring_like : &S.near_nodep, 1); else __sync_fetch_and_add(&S.near_dep, 1);
+        }
+        uint32_t maxl = 0;
+        for (uint32_t k = 0; k < n; ++k) if (lvl[k] > maxl) maxl = lvl[k];
+        __sync_fetch_and_add(&S.levels, maxl);
+        __sync_fetch_and_add(&S.level_hist[maxl < 39 ? maxl : 39], 1);
+        for (uint32_t l = 1; l <= maxl; ++l) {
+            uint32_t mx = 0, cnt = 0;
+            for (uint32_t k = 0; k < n; ++k) if (lvl[k] == l) { ++cnt; if (plen[k] > mx) mx = plen[k]; }
+            __sync_fetch_and_add(&S.ready_pieces, cnt);
+            __sync_fetch_and_add(&S.lvl_bytes, mx);
+            if (mx > kOwn) __sync_fetch_and_add(&S.team_levels, 1);
+        }
+        (void)any;
+    }
+}
+
+int main(int argc, char** argv)
+{
+    for (int i = 1; i < argc; ++i) {
+        FILE* f = fopen(argv[i], "rb"); if (!f) { perror(argv[i]); return 1; }
+        fseek(f, 0, SEEK_END); long sz = ftell(f); fseek(f, 0, SEEK_SET);
+        uint8_t* in = malloc(sz + 64); memset(in + sz, 0, 64);
+        if (fread(in, 1, sz, f) != (size_t)sz) return 1;
+        fclose(f);
+        uint32_t osz = DecompressedSize(in);
+        uint8_t* out = malloc((size_t)osz + 64);
+        memset(&S, 0, sizeof S);
+        int used = 0;
+        int rc = brotlig_oracle_decode((uint32_t)sz, in, &osz, out, 1, &used);
+        double pages = osz / 65536.0, R = (double)S.rounds, G = (double)S.groups;
+        printf("{\"file\": \"%s\", \"rc\": %d, \"ratio\": %.3f, \"pages\": %.0f, \"rounds_per_page\": %.1f, \"cmds_per_round\": %.2f, \"bytes_per_cmd\": %.2f, "
+               "\"lit_frac\": %.3f, \"lits_per_round\": %.1f, \"groups_per_round\": %.3f, \"slides_per_round\": %.3f, \"levels_per_group\": %.3f, "
+               "\"copy_pieces_per_group\": %.2f, \"far_direct\": %.3f, \"far_staged\": %.3f, \"far_staged_l1\": %.3f, \"near_nodep\": %.3f, \"near_dep\": %.3f, "
+               "\"short_lt8\": %.3f, \"overlap_lt32\": %.3f, \"ready_per_level\": %.2f, \"team_level_frac\": %.3f, \"maxlen_per_level\": %.1f, \"lit_pieces_per_group\": %.2f,\n",
+               argv[i], rc, (double)osz / sz, pages, R / pages, (double)S.cmds / R, (double)osz / S.cmds, (double)S.lit_bytes / osz, (double)S.lit_bytes / R,
+               G / R, (double)S.slides / R, (double)S.levels / G, (double)S.pieces_copy / G,
+               (double)S.far_direct / S.pieces_copy, (double)S.far_staged / S.pieces_copy, (double)S.ring_like / S.pieces_copy, (double)S.near_nodep / S.pieces_copy, (double)S.near_dep / S.pieces_copy,
+               (double)S.short_pieces / S.pieces_copy, (double)S.overlap_pieces / S.pieces_copy, (double)S.ready_pieces / (S.levels ? S.levels : 1),
+               (double)S.team_levels / (S.levels ? S.levels : 1), (double)S.lvl_bytes / (S.levels ? S.levels : 1), (double)S.lit_pieces / G);
+        printf(" \"level_hist\": [");
+        for (int l = 0; l < 12; ++l) printf("%s%.3f", l ? ", " : "", S.level_hist[l] / G);
+        printf("], \"ins_hist(0,1,2-3,4-7,8-15,16-31,32-127,128+)\": [");
+        for (int l = 0; l < 8; ++l) printf("%s%.3f", l ? ", " : "", (double)S.ins_hist[l] / S.cmds);
+        printf("], \"copy_hist\": [");
+        for (int l = 0; l < 8; ++l) printf("%s%.3f", l ? ", " : "", (double)S.copy_len_hist[l] / S.cmds);
+        printf("], \"dist_hist(<8,<32,<128,<528,<2k,<8k,<32k,more)\": [");
+        for (int l = 0; l < 8; ++l) printf("%s%.3f", l ? ", " : "", (double)S.dist_hist[l] / S.cmds);
+        printf("]}\n");
+        free(in); free(out);
+    }
+    return 0;
+}

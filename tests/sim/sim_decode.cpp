@@ -6,7 +6,7 @@
 #include <brotlig_wave_ops.h>
 
 #include "brotlig_kernels.h"
-#include "brotlig_split_kernels.h"
+#include "experimental/brotlig_split_kernels.h"
 
 using namespace brotlig;
 

@@ -107,6 +107,24 @@ def test_shard_plan_balances_compressed_bytes():
     assert api.ShardPlan([], 3) == [0, 0, 0, 0]
 
 
+def test_shard_plan_is_the_same_everywhere_and_even():
+    """The plan is host arithmetic: the pure-Python twin (shard.shard_plan, what a rank without hipcc uses) and the exports
+    of libbrotlig_hip.so and libbrotlig_cpu.so (one definition, csrc/brotlig_shard_plan.h) agree; equal streams are spread
+    evenly (10 streams over 4 ranks used to come out 3,3,3,1)."""
+    from brotli_g_sdk_amd import api, cpu, shard
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        n, g = int(rng.integers(0, 50)), int(rng.integers(1, 12))
+        sizes = [1] * n if trial % 4 == 0 else [int(x) for x in (rng.integers(1, 1000, n) if trial % 3 else rng.integers(1, 10, n) ** 6)]
+        py = shard.shard_plan(sizes, g)
+        assert py == api.ShardPlan(sizes, g) == cpu.ShardPlan(sizes, g), (sizes, g)
+        if trial % 4 == 0 and n >= g:
+            runs = [b - a for a, b in zip(py, py[1:])]
+            assert max(runs) - min(runs) <= 1, (n, g, runs)
+    assert [b - a for a, b in zip(*(lambda f: (f, f[1:]))(shard.shard_plan([1] * 10, 4)))] in ([3, 2, 3, 2], [3, 3, 2, 2], [2, 3, 2, 3])
+    assert shard.stream_indices(10, 4, 3) == list(range(8, 10))
+
+
 def test_multi_device_entry_checks_its_arguments_without_a_device():
     from brotli_g_sdk_amd import api
     L = api.lib()
@@ -115,3 +133,7 @@ def test_multi_device_entry_checks_its_arguments_without_a_device():
     assert L.BrotligDecodeBatchMultiDevice(ctypes.addressof(arr), 1, ctypes.sizeof(api.DeviceBatch) - 8, 0, 1, None, None) != 0   # stale struct
     assert L.BrotligDecodeBatchMultiDevice(ctypes.addressof(arr), 1, ctypes.sizeof(api.DeviceBatch), 0, 0, None, None) != 0       # no steps
     assert ctypes.sizeof(api.DeviceBatch) == 104
+    for fn in (L.BrotligDecodeBatchMultiDeviceAsync, L.BrotligDecodeBatchMultiDeviceWait):      # the non-blocking pair
+        assert fn(None, 1, ctypes.sizeof(api.DeviceBatch)) != 0
+        assert fn(ctypes.addressof(arr), 1, ctypes.sizeof(api.DeviceBatch) - 8) != 0
+        assert fn(ctypes.addressof(arr), 0, ctypes.sizeof(api.DeviceBatch)) != 0

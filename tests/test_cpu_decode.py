@@ -189,6 +189,39 @@ def test_whole_output_buffer_is_zeroed_like_the_reference():
     assert rc == 0 and osz.value == len(data) and np.array_equal(buf[:len(data)], data) and not buf[len(data):].any()
 
 
+def test_failed_and_aborted_decodes_leave_zeros_where_the_reference_would():
+    """The up-front memset of src/BrotligDecoder.cpp:448 is only performed where pages will not write (tail, textures); a page
+    that was never completed -- damaged, or skipped after an abort -- must still read as zeros afterwards, never as the
+    caller's old bytes."""
+    data = D.text(5 * 65536, 9)
+    s = E.encode(data).copy()
+    n_pages = 5
+    table = s[8:8 + 4 * n_pages].view("<u4")
+    # damage page 2: its ICP description becomes a `simple` code of one symbol, which both decoders reject
+    p2 = 8 + 4 * n_pages + int(table[2])
+    bad = s.copy()
+    bad[p2 + 4:p2 + 40] = 0xFF
+    cap = len(data) + 100
+    buf = np.full(cap, 0xC3, np.uint8)
+    osz = ctypes.c_uint32(cap)
+    rc = cpu.lib().BrotligDecodeCPU(len(bad), bad.ctypes.data, ctypes.byref(osz), buf.ctypes.data, 1)
+    _, ref = oracle_decode(bad)
+    if rc != 0:                                                     # (the damage is expected to be fatal for page 2)
+        assert not buf[len(data):].any()
+        for pg in range(n_pages):
+            got = buf[pg * 65536:(pg + 1) * 65536]
+            assert np.array_equal(got, data[pg * 65536:(pg + 1) * 65536]) or not got.any(), pg
+        assert not (buf == 0xC3).any()
+    # abort after the first page: completed pages stay, everything else is zero
+    seen = []
+    cb = cpu.FEEDBACK_PROC(lambda t, m, u: (seen.append(m), 1)[1])
+    buf[:] = 0xC3
+    osz = ctypes.c_uint32(cap)
+    rc = cpu.lib().BrotligDecodeCPUWithFeedback(len(s), s.ctypes.data, ctypes.byref(osz), buf.ctypes.data, 1, cb, None)
+    assert rc == cpu.BROTLIG_ABORTED and len(seen) == 1
+    assert np.array_equal(buf[:65536], data[:65536]) and not buf[65536:].any()
+
+
 def test_simple_code_with_one_symbol_is_rejected():
     """A `simple` prefix code announcing one symbol (NSYM field 0) indexes FixedCodelengths[-1] in the reference
     (BrotligHuffmanTable.cpp:103): undefined there, rejected here (and by the GPU kernel, tests/test_sim_decode.py)."""

@@ -1,4 +1,4 @@
-"""The split decode path (brotli_g_sdk_amd/csrc/brotlig_split_kernels.h) on the CPU simulator: the entropy kernel's command /
+"""The split decode path (brotli_g_sdk_amd/csrc/experimental/brotlig_split_kernels.h) on the CPU simulator: the entropy kernel's command /
 literal arrays are assembled by a few lines of Python here and must give the encoder's input; the assembly kernel must give the
 same bytes from the same arrays (test further down)."""
 import ctypes
