@@ -161,6 +161,9 @@ constexpr uint32_t kAblate = BROTLIG_ABLATE;
 #define BROTLIG_TUNE_WIN 1488
 #define BROTLIG_TUNE_DIST_LUT_BITS 8
 #endif
+#ifndef BROTLIG_TUNE_EARLY_NEAR
+#define BROTLIG_TUNE_EARLY_NEAR 1   // short near copies whose source is final before the group starts are read ahead, like far ones
+#endif
 constexpr int kLutBitsIcp = 8;
 constexpr int kLutBitsDist = BROTLIG_TUNE_DIST_LUT_BITS;
 constexpr int kLutBitsLit = 8;
@@ -1087,10 +1090,11 @@ struct FarSources {
     uint32_t stage_off;             // this lane's piece: 8-byte aligned offset into the staging area
     bool     direct, staged, any_staged, teams;
 };
-__device__ __forceinline__ FarSources fetch_far_sources(const uint8_t* out, uint32_t plen, uint32_t psrc, uint32_t far_len, uint32_t sl)
+__device__ __forceinline__ FarSources fetch_far_sources(const uint8_t* out, const uint8_t* win, uint32_t src_idx, bool near_direct,
+                                                        uint32_t plen, uint32_t psrc, uint32_t far_len, uint32_t sl)
 {
     FarSources f;
-    f.direct = far_len != 0u && far_len == plen && plen <= kShortCopy;
+    f.direct = (far_len != 0u && far_len == plen && plen <= kShortCopy) || near_direct;
     f.staged = far_len != 0u && !f.direct;
     const uint32_t stage_len = f.staged ? (far_len + 7u) & ~7u : 0u;
     f.any_staged = wave::any(f.staged);
@@ -1108,6 +1112,12 @@ __device__ __forceinline__ FarSources fetch_far_sources(const uint8_t* out, uint
         if (far_len > 8u) f.fe1 = load_u64u(s8 + min_u32(8u, lim));
         if (far_len > 16u) f.fe2 = load_u64u(s8 + min_u32(16u, lim));
         if (far_len > 24u) f.fe3 = load_u64u(s8 + min_u32(24u, lim));
+    }
+    if (near_direct) {      // the same from the window: the source lies below the group, so it is final, and whole in LDS
+        const uint8_t* s8 = win + src_idx;
+        f.fe0 = load_u64u(s8);
+        if (plen > 8u) f.fe1 = load_u64u(s8 + min_u32(8u, clip8));
+        if (plen > 16u) { f.fe2 = load_u64u(s8 + min_u32(16u, clip8)); f.fe3 = load_u64u(s8 + clip8); }
     }
     if (f.teams) {
         const uint32_t staged_mask = wave::half_ballot(f.staged);
@@ -1578,7 +1588,12 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             // Everything else that reaches below the window is staged: longer pieces, and patterns that straddle
             // the window boundary.  Staged pieces of up to kShortCopy bytes are fetched by their own lane too; as
             // soon as one is longer, all staged pieces get teams of lanes (two chunks per lane now, the rest later).
-            const FarSources far = fetch_far_sources(job.out, plen, psrc, far_len, sl);
+            // Round 4: the same for a short piece whose source lies in the window but wholly below the group (final before the
+            // group started -- 27 % of the copy pieces of the mixed data, most of the first dependency level): read ahead from LDS
+            // into the same registers and stored with the far pieces, instead of a level of its own.
+            const bool near_direct = BROTLIG_TUNE_EARLY_NEAR && plen != 0u && far_len == 0u && plen <= kShortCopy && dist >= plen &&
+                                     src_end <= gpos && !(kAblate & kAblLevels);
+            const FarSources far = fetch_far_sources(job.out, L.win, psrc - view.win_base, near_direct, plen, psrc, far_len, sl);
             const bool far_direct = far.direct;
             const uint32_t stage_off = far.stage_off;
             clk.lap(kPhPieces);
@@ -1589,7 +1604,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             // exact dependencies of my copy piece: the pieces (of commands before me) that own bytes of its source range
             // inside this group; everything below the group is final
             const uint32_t dep_mask = piece_dependencies(L.start_bits, L.start_cum, on, in_group, (rel0 > g0 ? rel0 : g0) - g0, gpos,
-                                                         psrc, src_end, plen != 0u && !(kAblate & kAblDeps), sl, clk);
+                                                         psrc, src_end, plen != 0u && !far_direct && !(kAblate & kAblDeps), sl, clk);
             clk.lap(kPhCopyFence);
 
             // -- 4. literals of the group.  Literal j of the round comes from sub-stream j mod 32 and is

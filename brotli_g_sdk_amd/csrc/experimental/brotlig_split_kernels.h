@@ -423,7 +423,7 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
             // Everything else that reaches below the window is staged: longer pieces, and patterns that straddle
             // the window boundary.  Staged pieces of up to kShortCopy bytes are fetched by their own lane too; as
             // soon as one is longer, all staged pieces get teams of lanes (two chunks per lane now, the rest later).
-            const FarSources far = fetch_far_sources(job.out, plen, psrc, far_len, sl);
+            const FarSources far = fetch_far_sources(job.out, nullptr, 0u, false, plen, psrc, far_len, sl);
             const bool far_direct = far.direct;
             const uint32_t stage_off = far.stage_off;
             clk.lap(kPhPieces);

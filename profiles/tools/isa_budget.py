@@ -61,7 +61,9 @@ def classify(op):
         return "VALU"
     if op.startswith("ds_"):
         return "LDS"
-    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+    if op.startswith("scratch_"):
+        return "SCRATCH"
+    if op.startswith(("global_", "buffer_", "flat_")):
         return "VMEM"
     if op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_swappc", "s_endpgm")):
         return "BRANCH"
@@ -206,16 +208,16 @@ def main():
             fn, f, ln = st[0]
             line_detail[(fn.split("<")[0], ln)][cls] += 1
 
-    classes = ["VALU", "SALU", "BRANCH", "WAIT", "LDS", "VMEM", "SMEM", "OTHER"]
+    classes = ["VALU", "SALU", "BRANCH", "WAIT", "LDS", "VMEM", "SCRATCH", "SMEM", "OTHER"]
     print(f"kernel {sym}: {len(insts)} instructions, {size} bytes (-g) / {size_n} bytes (no -g){'' if same else '  ** SIZES DIFFER: -g changed the code **'}")
-    print(f"{'stage':36s} " + " ".join(f"{c:>6s}" for c in classes) + "   total")
+    print(f"{'stage':36s} " + " ".join(f"{c:>7s}" for c in classes) + "   total")
     order = ["0 wave setup"] + [m[0] for m in marks[:-1]]
     tot = collections.Counter()
     for s in order:
         c = per_stage.get(s, collections.Counter())
-        print(f"{s:36s} " + " ".join(f"{c[k]:6d}" for k in classes) + f"  {sum(c.values()):6d}")
+        print(f"{s:36s} " + " ".join(f"{c[k]:7d}" for k in classes) + f"  {sum(c.values()):6d}")
         tot.update(c)
-    print(f"{'TOTAL':36s} " + " ".join(f"{tot[k]:6d}" for k in classes) + f"  {sum(tot.values()):6d}")
+    print(f"{'TOTAL':36s} " + " ".join(f"{tot[k]:7d}" for k in classes) + f"  {sum(tot.values()):6d}")
     if a.blocks:
         print("\nloops (innermost attribution; address range, back-edge source):")
         for key in sorted(per_loop):

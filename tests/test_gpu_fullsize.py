@@ -70,3 +70,21 @@ def test_config4_bc3_4gib_full_size(api):
     assert rc == 0
     assert np.array_equal(dec.output(0), ref)
     assert np.array_equal(dec.output(255), expected[255])
+
+
+def test_config5_32gib_eight_shards_on_the_one_device(api):
+    """configs[4] of BASELINE.json: 32 GiB of 64 KiB pages -- streams 0..127 of the mixed class, 4096 pages each -- cut into
+    8 shards by BrotligShardPlan and decoded shard by shard through BrotligDecodeBatchMultiDevice on the one visible device
+    (the reference's fan-out: src/BrotligDecoder.cpp:356-375).  Every tiled repeat of every stream is
+    compared with the bytes it was encoded from.  The per-shard times it collects are the labelled one-device projection
+    (profiles/tools/config5_projection.py writes them to profiles/); here only the properties are asserted."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    import config5_projection as P
+    r = P.run(shards=8, streams_per_shard=16, pages=4096, distinct=256, steps=1, warmup=0)
+    assert r["bit_exact"]
+    assert r["total_decompressed_bytes"] == 32 * 2**30 and len(r["shards"]) == 8
+    assert [s["streams"][0] for s in r["shards"]] == sorted(s["streams"][0] for s in r["shards"])
+    assert r["shards"][0]["streams"][0] == 0 and r["shards"][-1]["streams"][1] == 127
+    # shards are balanced by compressed bytes: none carries more than 1.25 x its share
+    assert r["shard_imbalance_compressed"] < 1.25, r["shard_imbalance_compressed"]
+    assert "projection" in r["label"] and r["projected_GBps_kernel"] > r["one_device_GBps_kernel"]
