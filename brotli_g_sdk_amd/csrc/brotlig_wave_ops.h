@@ -22,8 +22,10 @@ __device__ __forceinline__ uint32_t lane_id_fresh()
 }
 
 // ---- wave scope -------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
-__device__ __forceinline__ bool any(bool p) { return __ballot(p) != 0ull; }
+// (the i1 form of the ballot: HIP's __ballot(int) widens the predicate to 0 / 1 and compares it again -- a v_cndmask and a
+// v_cmp per call on top of the compare that produced the predicate; round 4, ~40 ballots per round)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // Value of `v` in lane `src` (0..63) of the wave.
 __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src)
 {
@@ -37,7 +39,7 @@ __device__ __forceinline__ unsigned long long clock() { return (unsigned long lo
 // 32-bit ballot of the caller's half.
 __device__ __forceinline__ uint32_t half_ballot(bool p)
 {
-    const uint64_t m = __ballot(p);
+    const uint64_t m = __builtin_amdgcn_ballot_w64(p);
     return (uint32_t)(m >> (lane_id() & 32u));
 }
 

@@ -19,6 +19,8 @@ static struct {
     uint64_t multi_group_rounds, slides, ring_like;
     uint64_t lvl_bytes; /* sum over levels of max piece length in the level */
     uint64_t levels64; /* levels if 64 consecutive commands were one step */
+    uint64_t simple_groups, simple_groups_long; /* groups whose copy pieces are all direct-eligible (<=32 bytes / any length) */
+    uint64_t ingroup_pieces, long_pieces;
 } S;
 static __thread uint32_t t_win_base, t_page_out;
 static int bucket(uint32_t v) { return v == 0 ? 0 : v < 2 ? 1 : v < 4 ? 2 : v < 8 ? 3 : v < 16 ? 4 : v < 32 ? 5 : v < 128 ? 6 : 7; }
@@ -47,7 +49,7 @@ static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_po
         __sync_fetch_and_add(&S.groups, 1);
         /* pieces */
         uint32_t lvl[32], plen[32], first = 32;
-        int any = 0;
+        int any = 0, not_simple = 0, not_simple_long = 0;
         for (uint32_t k = 0; k < n; ++k) {
             lvl[k] = 0; plen[k] = 0;
             uint32_t r0 = rel0[k], t = q[k].insert_len + q[k].copy_len, cs = r0 + q[k].insert_len;
@@ -62,6 +64,12 @@ static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_po
             uint32_t far_len = psrc < t_win_base ? (pattern < t_win_base - psrc ? pattern : t_win_base - psrc) : 0;
             __sync_fetch_and_add(&S.pieces_copy, 1);
             if (pl < 8) __sync_fetch_and_add(&S.short_pieces, 1);
+            {   /* direct-eligible: source final before the group starts, no self-overlap, in one place */
+                int whole = far_len == 0 || far_len == pl;
+                int below = src_end <= gpos && q[k].dist >= pl && whole;
+                if (!below) { not_simple = 1; not_simple_long = 1; __sync_fetch_and_add(&S.ingroup_pieces, 1); }
+                else if (pl > kShort) { not_simple = 1; __sync_fetch_and_add(&S.long_pieces, 1); }
+            }
             if (far_len && far_len == pl && pl <= kShort) { __sync_fetch_and_add(&S.far_direct, 1); continue; }
             if (far_len) __sync_fetch_and_add(&S.far_staged, 1);
             plen[k] = pl;
@@ -89,6 +97,8 @@ static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_po
             if (mx > kOwn) __sync_fetch_and_add(&S.team_levels, 1);
         }
         (void)any;
+        if (!not_simple) __sync_fetch_and_add(&S.simple_groups, 1);
+        if (!not_simple_long) __sync_fetch_and_add(&S.simple_groups_long, 1);
     }
 }
 
@@ -109,10 +119,11 @@ int main(int argc, char** argv)
         printf("{\"file\": \"%s\", \"rc\": %d, \"ratio\": %.3f, \"pages\": %.0f, \"rounds_per_page\": %.1f, \"cmds_per_round\": %.2f, \"bytes_per_cmd\": %.2f, "
                "\"lit_frac\": %.3f, \"lits_per_round\": %.1f, \"groups_per_round\": %.3f, \"slides_per_round\": %.3f, \"levels_per_group\": %.3f, "
                "\"copy_pieces_per_group\": %.2f, \"far_direct\": %.3f, \"far_staged\": %.3f, \"far_staged_l1\": %.3f, \"near_nodep\": %.3f, \"near_dep\": %.3f, "
-               "\"short_lt8\": %.3f, \"overlap_lt32\": %.3f, \"ready_per_level\": %.2f, \"team_level_frac\": %.3f, \"maxlen_per_level\": %.1f, \"lit_pieces_per_group\": %.2f,\n",
+               "\"simple_groups\": %.3f, \"simple_groups_anylen\": %.3f, \"ingroup_src_pieces_per_group\": %.2f, \"long_below_pieces_per_group\": %.2f, \"short_lt8\": %.3f, \"overlap_lt32\": %.3f, \"ready_per_level\": %.2f, \"team_level_frac\": %.3f, \"maxlen_per_level\": %.1f, \"lit_pieces_per_group\": %.2f,\n",
                argv[i], rc, (double)osz / sz, pages, R / pages, (double)S.cmds / R, (double)osz / S.cmds, (double)S.lit_bytes / osz, (double)S.lit_bytes / R,
                G / R, (double)S.slides / R, (double)S.levels / G, (double)S.pieces_copy / G,
                (double)S.far_direct / S.pieces_copy, (double)S.far_staged / S.pieces_copy, (double)S.ring_like / S.pieces_copy, (double)S.near_nodep / S.pieces_copy, (double)S.near_dep / S.pieces_copy,
+               S.simple_groups / G, S.simple_groups_long / G, S.ingroup_pieces / G, S.long_pieces / G,
                (double)S.short_pieces / S.pieces_copy, (double)S.overlap_pieces / S.pieces_copy, (double)S.ready_pieces / (S.levels ? S.levels : 1),
                (double)S.team_levels / (S.levels ? S.levels : 1), (double)S.lvl_bytes / (S.levels ? S.levels : 1), (double)S.lit_pieces / G);
         printf(" \"level_hist\": [");

@@ -68,7 +68,7 @@ def precon_cases():
 
 def far_boundary(n, seed, dlo, dhi, lit=8, cpy=24):
     """Literal runs of `lit` fresh bytes followed by copies of `cpy` bytes from a distance in [dlo, dhi]: with the
-    distances around the decoder's on-chip history (kHist = 528 bytes) every copy reads bytes the window has just
+    distances around the decoder's on-chip history (kHist = 656 bytes since round 4, 528 before) every copy reads bytes the window has just
     given up -- from global memory, where an earlier group of the same wavefront flushed them moments before --
     or straddles the window boundary."""
     rng = np.random.default_rng(seed)
@@ -89,7 +89,10 @@ def raw_stress_cases():
     the previous assembly group.  (name, data thunk, encoder kwargs)."""
     out = []
     for k, (dlo, dhi, lit, cpy) in enumerate([(513, 560, 8, 24), (529, 544, 4, 28), (529, 1100, 8, 24), (520, 540, 1, 63),
-                                               (528, 536, 16, 16), (1000, 1100, 8, 120)]):
+                                               (528, 536, 16, 16), (1000, 1100, 8, 120),
+                                               # round 4: groups of 640 bytes, 656 bytes of history
+                                               (641, 700, 8, 24), (657, 672, 4, 28), (657, 1400, 8, 24), (648, 668, 1, 63),
+                                               (656, 664, 16, 16)]):
         for page in (65536, 131072):
             out.append((f"far_{dlo}_{dhi}_{lit}_{cpy}_{page >> 10}k",
                         (lambda a=dlo, b=dhi, l=lit, c=cpy, s=k: far_boundary(4 * 131072 + 777, 40 + s, a, b, l, c)),

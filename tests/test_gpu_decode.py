@@ -53,8 +53,8 @@ def test_decode_gpu_preconditioned(api, name, thunk, pre):
 
 @pytest.mark.parametrize("name,thunk,kw", raw_stress_cases(), ids=[c[0] for c in raw_stress_cases()])
 def test_far_copies_read_what_the_previous_group_flushed(api, name, thunk, kw):
-    """Global read-after-write inside a wavefront: the decoder keeps 528 bytes of history on chip and flushes the
-    window group by group; copies from 513..1100 bytes back read global memory that the same wavefront stored one
+    """Global read-after-write inside a wavefront: the decoder keeps 656 bytes of history on chip (528 until round 3) and flushes
+    the window group by group; copies from 513..1400 bytes back read global memory that the same wavefront stored one
     group earlier, with no fence in between (the design argument is in brotlig_kernels.h, step 3b).  Four streams
     side by side so that several wavefronts run the pattern at once; bit-exact against the oracle."""
     data = thunk()

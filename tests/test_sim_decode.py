@@ -19,6 +19,13 @@ CSRC = os.path.join(ROOT, "brotli_g_sdk_amd", "csrc")
 
 
 def build_sim(name, flags=()):
+    # BROTLIG_SIM_FLAGS="-DBROTLIG_TUNE_X=1 ...": the whole simulator suite on a non-default build of the kernel source
+    # (how the A/B variants of profiles/tools/ab_variants.sh are checked for bit-exactness before they go to the GPU box)
+    extra = os.environ.get("BROTLIG_SIM_FLAGS", "").split()
+    if extra:
+        import hashlib
+        name = name.replace(".so", "_" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8] + ".so")
+        flags = list(flags) + extra
     so = os.path.join(SIM_DIR, name)
     srcs = [os.path.join(SIM_DIR, f) for f in ("sim_decode.cpp", "sim_runtime.cpp")]
     deps = srcs + [os.path.join(SIM_DIR, f) for f in ("sim_runtime.h", "brotlig_wave_ops.h")] + \
