@@ -2050,7 +2050,13 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
     decode_pages<kProf>(W, a, prof_lds);
 }
 
-__global__ void __launch_bounds__(64, 4) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }
+// BROTLIG_TUNE_WAVES_PER_SIMD (diagnostics, profiles/r04_isa_stage_budget.md): the register budget of 5 (96 VGPRs) or 6 (80) wavefronts per
+// SIMD instead of the 4 (128) the kernel is built for -- only honoured by the compiler when the LDS size allows that occupancy too
+// (build with a smaller window / group / LUTs, e.g. -DBROTLIG_TUNE_ROUND_MAX=384 -DBROTLIG_TUNE_HIST=400 -DBROTLIG_TUNE_WIN=800 ...).
+#ifndef BROTLIG_TUNE_WAVES_PER_SIMD
+#define BROTLIG_TUNE_WAVES_PER_SIMD 4
+#endif
+__global__ void __launch_bounds__(64, BROTLIG_TUNE_WAVES_PER_SIMD) brotlig_decode_kernel(DecodeArgs a) { decode_kernel_body<false>(a); }
 // Diagnostics twin: same code with s_memtime phase timers (BrotligDecodePhaseProfile).
 __global__ void __launch_bounds__(64, 4) brotlig_decode_kernel_timed(DecodeArgs a) { decode_kernel_body<true>(a); }
 
