@@ -902,6 +902,40 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
 // level without long pieces runs one lane per piece; otherwise the ready pieces share the 32 lanes as teams, 8 bytes per
 // lane per step.  Overlapping copies replay their pattern modulo the distance, so a copy never waits for itself.
 // Pieces with `far_direct` went from registers straight to their place and take no part.
+#ifndef BROTLIG_TUNE_PLAIN_LEVELS
+#define BROTLIG_TUNE_PLAIN_LEVELS 1
+#endif
+// The same for a group in which every piece that takes part is simple and at most 32 bytes long (decided once per group by the
+// caller, for both halves): a level is then one batch of own-lane chunk copies and nothing else -- no question about teams, about
+// further batches or about the overlap path in any iteration.  (Round 4: those three questions are ~19 of a level's ~90 issued
+// instructions, 3.7 levels a round; text pages take this path in nearly every group.)
+template <class Clock>
+__device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* stage, uint32_t plen, uint32_t far_len, uint32_t stage_off,
+                                                  uint32_t src_idx, uint32_t dst_idx, bool far_direct, uint32_t dep_mask, uint32_t sl, Clock& clk)
+{
+    const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
+    const uint8_t* const sp = far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx;
+    uint8_t* const dp = win + dst_idx;
+    uint32_t todo = wave::half_ballot(plen != 0u && !far_direct);
+    while (wave::any(todo != 0u)) {
+        clk.count(kPhLevels, 1);
+        clk.halves(kPhLevelHalves, todo != 0u);
+        const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
+        const uint32_t ready_mask = wave::half_ballot(ready);
+        if (ready) {
+            if (plen >= 8u) {
+                const Chunks32 c = load_chunks32(sp, plen, clip8);
+                store_chunks32(dp, c, plen, clip8);
+            } else {
+                store_bytes(dp, load_u64u(sp), plen);
+            }
+        }
+        clk.lap(kPhLvShort);
+        todo &= ~ready_mask;
+        wave::sync();
+    }
+}
+
 template <class Clock>
 __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage, uint32_t plen, uint32_t dist, uint32_t far_len, uint32_t stage_off,
                                             uint32_t src_idx, uint32_t dst_idx, bool far_direct, uint32_t dep_mask, uint32_t sl, Clock& clk)
@@ -1682,7 +1716,18 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             //        port (s_setprio; +1.2 .. 1.5 % measured, any level 1..3; raised around the command decode as well it is
             //        the same on mixed data and +0.6 % on text, around the whole group loop it loses)
             wave::set_priority(1);
+#if BROTLIG_TUNE_PLAIN_LEVELS
+            {   // one question per group instead of three per level: does any piece need more than the plain own-lane batch?
+                const uint32_t pat = min_u32(plen, dist);
+                const bool plain_piece = (far_len == 0u || far_len == pat) && dist >= plen && plen <= 32u;      // simple, and one batch
+                if (!kAblate && !wave::any(plen != 0u && !far_direct && !plain_piece))
+                    copy_levels_plain(L.win, L.stage, plen, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
+                else
+                    copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
+            }
+#else
             copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
+#endif
             wave::set_priority(0);
             clk.lap(kPhCopyLevels);
         }
