@@ -184,9 +184,7 @@ def ShardPlan(in_sizes, num_shards):
     return [int(x) for x in first]
 
 
-def DecodeBatchMultiDevice(decoders, warmup=0, steps=1, streams=None):
-    """BrotligDecodeBatchMultiDevice over `decoders` (BatchDecoder objects, one per shard, each on its own device -- or
-    several on one).  Returns (max kernel ms, max wall ms, per-shard list of (result, kernel_ms, wall_ms))."""
+def _device_batches(decoders, streams):
     n = len(decoders)
     arr = (DeviceBatch * n)()
     for i, d in enumerate(decoders):
@@ -199,6 +197,14 @@ def DecodeBatchMultiDevice(decoders, warmup=0, steps=1, streams=None):
         b.d_workspace, b.workspace_bytes = d.d_ws.data_ptr(), d.ws_bytes
         b.d_scratch = d.d_scratch.data_ptr() if d.d_scratch is not None else None
         b.hip_stream = streams[i] if streams is not None else None
+    return arr
+
+
+def DecodeBatchMultiDevice(decoders, warmup=0, steps=1, streams=None):
+    """BrotligDecodeBatchMultiDevice over `decoders` (BatchDecoder objects, one per shard, each on its own device -- or
+    several on one).  Returns (max kernel ms, max wall ms, per-shard list of (result, kernel_ms, wall_ms))."""
+    n = len(decoders)
+    arr = _device_batches(decoders, streams)
     mk, mw = ctypes.c_double(0.0), ctypes.c_double(0.0)
     rc = lib().BrotligDecodeBatchMultiDevice(ctypes.addressof(arr), n, ctypes.sizeof(DeviceBatch), int(warmup), int(steps),
                                              ctypes.byref(mk), ctypes.byref(mw))
@@ -206,6 +212,26 @@ def DecodeBatchMultiDevice(decoders, warmup=0, steps=1, streams=None):
     if rc != BROTLIG_OK:
         raise BrotligError(rc, "BrotligDecodeBatchMultiDevice")
     return mk.value, mw.value, per
+
+
+class MultiDeviceAsync:
+    """The non-blocking pair BrotligDecodeBatchMultiDeviceAsync / ...Wait: enqueue every shard on its device and stream and
+    return; wait() collects the batch status of each shard.  No host thread is created, nothing is timed."""
+
+    def __init__(self, decoders, streams=None):
+        self.n = len(decoders)
+        self.arr = _device_batches(decoders, streams)
+        self.keep = (decoders, streams)
+        rc = lib().BrotligDecodeBatchMultiDeviceAsync(ctypes.addressof(self.arr), self.n, ctypes.sizeof(DeviceBatch))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligDecodeBatchMultiDeviceAsync")
+
+    def wait(self):
+        rc = lib().BrotligDecodeBatchMultiDeviceWait(ctypes.addressof(self.arr), self.n, ctypes.sizeof(DeviceBatch))
+        results = [self.arr[i].result for i in range(self.n)]
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligDecodeBatchMultiDeviceWait")
+        return results
 
 
 def DeviceSelfTest():

@@ -483,6 +483,21 @@ __device__ __forceinline__ Team make_team(uint32_t job_mask, uint32_t sl)
     return t;
 }
 
+// The same over all 64 lanes of a wavefront that decodes ONE page (small batches: the upper half has no page of its own, see
+// decode_pages): `job_mask` = the ready pieces of the lower half, `lane` = 0..63; each job gets 64 >> ceil_log2(count) lanes.
+__device__ __forceinline__ Team make_team64(uint32_t job_mask, uint32_t lane)
+{
+    const uint32_t count = (uint32_t)__popc(job_mask);
+    const uint32_t need = count <= 1u ? 0u : 32u - (uint32_t)__clz((int)(count - 1u));
+    Team t;
+    t.log2_size = 6u - need;
+    const uint32_t q = lane >> t.log2_size;
+    t.member = lane & ((1u << t.log2_size) - 1u);
+    t.serves = q < count;
+    t.job = select_bit(job_mask, t.serves ? q : 0u);
+    return t;
+}
+
 // Store window bytes [from, to) of the page to global memory: up to 15 head bytes, then aligned
 // 16-byte pieces (one per lane per step), then -- only when `exact` -- the tail bytes.  Without
 // `exact` the range is cut at the last 16-byte boundary.  Returns the new flushed position.
@@ -938,7 +953,7 @@ __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* 
 
 template <class Clock>
 __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage, uint32_t plen, uint32_t dist, uint32_t far_len, uint32_t stage_off,
-                                            uint32_t src_idx, uint32_t dst_idx, bool far_direct, uint32_t dep_mask, uint32_t sl, Clock& clk)
+                                            uint32_t src_idx, uint32_t dst_idx, bool far_direct, uint32_t dep_mask, uint32_t sl, bool solo, Clock& clk)
 {
     const uint32_t pattern = min_u32(plen, dist);
     const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
@@ -1022,14 +1037,31 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             }
         } else {
         clk.count(kPhTeamLevels, 1);
-        const Team t = make_team(ready_mask, sl);
-        const uint32_t t_pk = wave::half_shfl(packed, t.job), t_dist = wave::half_shfl(dist, t.job);
-        const uint32_t t_src = wave::half_shfl(src_idx, t.job), t_dst = wave::half_shfl(dst_idx, t.job);
+        // Small batches (round 4): a wavefront that decodes one page lends the idle upper half to the teams -- twice the lanes
+        // per long piece.  The upper lanes address the lower half's LDS record (the two are adjacent in WaveLds) and take the
+        // pieces' fields from the lower half's lanes.
+        Team t;
+        uint32_t t_pk, t_dist, t_src, t_dst, team_mask = ready_mask;
+        uint8_t* t_lds = win;
+        const uint8_t* t_stg = reinterpret_cast<const uint8_t*>(stage);
+        if (solo) {
+            const uint32_t lane = wave::lane_id();
+            team_mask = wave::bcast(ready_mask, 0u);
+            t = make_team64(team_mask, lane);
+            t_pk = wave::bcast(packed, t.job); t_dist = wave::bcast(dist, t.job);
+            t_src = wave::bcast(src_idx, t.job); t_dst = wave::bcast(dst_idx, t.job);
+            const uint32_t back = lane >= 32u ? (uint32_t)sizeof(PageLds) : 0u;
+            t_lds = win - back; t_stg -= back;
+        } else {
+            t = make_team(ready_mask, sl);
+            t_pk = wave::half_shfl(packed, t.job); t_dist = wave::half_shfl(dist, t.job);
+            t_src = wave::half_shfl(src_idx, t.job); t_dst = wave::half_shfl(dst_idx, t.job);
+        }
         const uint32_t t_len = t_pk & 0x7FFu, t_far = (t_pk >> 11) & 0x7FFu;
-        const uint8_t* t_stage = reinterpret_cast<const uint8_t*>(stage) + ((t_pk >> 22) << 3);
-        const uint8_t* t_win = win + (int32_t)t_src;
-        uint8_t* t_out = win + t_dst;
-        const bool act = t.serves && ready_mask != 0u;
+        const uint8_t* t_stage = t_stg + ((t_pk >> 22) << 3);
+        const uint8_t* t_win = t_lds + (int32_t)t_src;
+        uint8_t* t_out = t_lds + t_dst;
+        const bool act = t.serves && team_mask != 0u;
         const uint32_t t_pat = t_dist < t_len ? t_dist : t_len;
         const bool whole = t_far == 0u || t_far == t_pat;    // pattern in one place (window or staging area)
         const uint8_t* t_base = t_far ? t_stage : t_win;
@@ -1471,7 +1503,7 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
 // stays uniform: one iteration = (page start for the halves that need one) + (one round for the
 // halves inside a page) + (page end for the halves whose page just finished), each under per-half
 // predicates.
-template <bool kProf>
+template <bool kProf, bool kSolo>
 __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned long long* prof_lds)
 {
     PhaseClock<kProf> clk;
@@ -1490,15 +1522,10 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
     // ---- per-half state of the page under construction
     PageJob job = fetch_job(a, nullptr, 0u, false);
     bool live = false;               // inside a compressed page
-    // Small batches: with fewer pages than half-waves a page decodes fastest ALONE in its wavefront (no lock-step with a
-    // neighbour: every phase of a round costs the maximum over the two halves).  So the upper halves only take part in as many
-    // wavefronts as there are pages beyond one per wavefront; from two pages per wavefront on, every half works.
-    bool finished = false;           // the work counter ran out for this half (or it sits this launch out)
-    {
-        const uint32_t total0 = a.page_base[a.num_streams];
-        const uint32_t doubles = total0 > gridDim.x ? total0 - gridDim.x : 0u;     // wavefronts that need both halves
-        if (lane >= 32u && blockIdx.x >= doubles) finished = true;
-    }
+    // kSolo (chosen per wavefront by decode_kernel_body): this wavefront decodes one page at a time, its upper half takes no pages
+    // and helps with long copies instead.  A template parameter, not a flag: the two-page instantiation is compiled without it.
+    constexpr bool solo = kSolo;
+    bool finished = lane >= 32u && solo;    // the work counter ran out for this half (or it sits this launch out)
     BitReader br;
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
     DistanceRing ring;
@@ -1723,10 +1750,10 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
                 if (!kAblate && !wave::any(plen != 0u && !far_direct && !plain_piece))
                     copy_levels_plain(L.win, L.stage, plen, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
                 else
-                    copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
+                    copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, solo, clk);
             }
 #else
-            copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
+            copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, solo, clk);
 #endif
             wave::set_priority(0);
             clk.lap(kPhCopyLevels);
@@ -2092,7 +2119,13 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
         __shared__ unsigned long long prof_acc[kNumPhases];
         prof_lds = prof_acc;
     }
-    decode_pages<kProf>(W, a, prof_lds);
+    // Small batches: with fewer pages than half-waves a page decodes fastest ALONE in its wavefront (no lock-step with a
+    // neighbour: every phase of a round costs the maximum over the two halves).  So the upper halves only take part in as many
+    // wavefronts as there are pages beyond one per wavefront; from two pages per wavefront on, every half works.
+    const uint32_t total0 = a.page_base[a.num_streams];
+    const uint32_t doubles = total0 > gridDim.x ? total0 - gridDim.x : 0u;     // wavefronts that need both halves
+    if (blockIdx.x >= doubles) decode_pages<kProf, true>(W, a, prof_lds);
+    else decode_pages<kProf, false>(W, a, prof_lds);
 }
 
 // BROTLIG_TUNE_WAVES_PER_SIMD (diagnostics, profiles/r04_isa_stage_budget.md): the register budget of 5 (96 VGPRs) or 6 (80) wavefronts per

@@ -325,6 +325,21 @@ def test_multi_device_entry_with_three_shards_on_the_one_device(api):
         api.DecodeBatchMultiDevice(decs2)
     torch.cuda.synchronize()
     assert np.array_equal(decs2[1].output(0), datas[1])
+    # the non-blocking pair: enqueue all shards, do something else, collect the status
+    for d in decs:
+        d.poison_output()
+    torch.cuda.synchronize()
+    job = api.MultiDeviceAsync(decs, streams=[s.cuda_stream for s in side])
+    filler = torch.ones(1 << 20, device="cuda").sum()                      # the caller's own work, meanwhile
+    assert job.wait() == [0, 0, 0] and float(filler) == float(1 << 20)
+    k = 0
+    for d in decs:
+        for i in range(d.n):
+            assert np.array_equal(d.output(i), datas[k]), k
+            k += 1
+    job2 = api.MultiDeviceAsync(decs2)
+    with pytest.raises(api.BrotligError):
+        job2.wait()
 
 
 def test_context_decodes_assets_of_growing_and_shrinking_size(api):

@@ -52,7 +52,7 @@ def sim_small_caps():
     return build_sim("libbrotlig_sim_smallcaps.so", ["-DBROTLIG_ICP_SYM_CAP=24", "-DBROTLIG_DIST_SYM_CAP=9"])
 
 
-def run_batch(sim, streams, sizes, precon=False):
+def run_batch(sim, streams, sizes, precon=False, grid=3):
     in_offs, pos = [], 0
     for s in streams:
         in_offs.append(pos)
@@ -69,7 +69,7 @@ def run_batch(sim, streams, sizes, precon=False):
     io, oo = np.array(in_offs, np.uint64), np.array(out_offs, np.uint64)
     st = ctypes.c_uint32(0)
     sim.sim_decode_batch(buf.ctypes.data, pos, out.ctypes.data, opos, scratch.ctypes.data if precon else None,
-                         io.ctypes.data, oo.ctypes.data, len(streams), 3, ctypes.byref(st))
+                         io.ctypes.data, oo.ctypes.data, len(streams), grid, ctypes.byref(st))
     assert np.all(out[opos:] == 0xCD)
     return [out[o:o + n] for o, n in zip(out_offs, sizes)], st.value
 
@@ -104,6 +104,23 @@ def test_sim_batch_of_streams(sim):
     assert status == 0
     for o, d in zip(outs, datas):
         assert np.array_equal(o, d)
+
+
+def test_sim_one_page_per_wavefront_lends_the_upper_half_to_the_teams(sim):
+    """Small batches: while a launch has no more pages than wavefronts every page decodes alone in its wavefront, and the idle
+    upper half joins the copy teams of long pieces (round 4: 64 lanes per team set, `make_team64`).  Long runs, long record
+    copies and long self-overlapping copies, with as many wavefronts as pages (all alone), with fewer (some paired, some alone)
+    and with one wavefront for everything (all paired): the same bytes every time."""
+    rng = np.random.default_rng(77)
+    long_overlaps = np.concatenate([np.tile(rng.integers(0, 256, int(d), dtype=np.uint8), 1 + 900 // int(d))[:900] for d in rng.integers(1, 40, 80)])
+    datas = [D.runs(3 * 65536, 21), D.records(2 * 65536 + 123, 22), long_overlaps, D.mixed(2 * 65536, 23)]
+    streams = [E.encode(d) for d in datas]
+    pages = sum((len(d) + 65535) // 65536 for d in datas)
+    for grid in (pages, pages - 3, 1):
+        outs, status = run_batch(sim, streams, [len(d) for d in datas], grid=grid)
+        assert status == 0
+        for o, d in zip(outs, datas):
+            assert np.array_equal(o, d), grid
 
 
 def test_sim_bad_header_sets_status(sim):
