@@ -4,6 +4,7 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from brotli_g_sdk_amd import api
+bench.ENCODER_FLAGS = int(os.environ.get("BROTLIG_ENCODER_FLAGS", "0"))      # 192: the optimal-parse streams bench.py reports as `alt`
 kind = sys.argv[1] if len(sys.argv) > 1 else "mixed"
 nstreams = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 streams, _ = bench.build_streams(kind, range(nstreams), 2048, 128)
@@ -18,5 +19,5 @@ out["halves_per_level"] = round(p["level_halves"] / max(p["levels"], 1), 3)
 out["halves_per_group"] = round(p["group_halves"] / max(p["groups"], 1), 3)
 out["cycles_per_round"] = round(tot / max(p["rounds"], 1), 1)
 out["pages"] = int(sum(api.DecompressedSize(s) for s in streams) // 65536)
-out["workload"] = kind
+out["workload"] = kind + ("" if not bench.ENCODER_FLAGS else f" (encoder flags {bench.ENCODER_FLAGS})")
 print(json.dumps(out))

@@ -20,7 +20,9 @@ python bench.py --distinct 4096 --no-cpu-baseline > "$out/bench_distinct4096.jso
 python profiles/tools/latency.py > "$out/latency.json" 2>> "$out/bench.err"
 python profiles/tools/streamer_bench.py > "$out/streamer_bench.json" 2>> "$out/bench.err"
 python profiles/tools/cpu_decode_bench.py > "$out/cpu_decode.json" 2>> "$out/bench.err"
-for k in "mixed 16" "text 16" "runs 16" "bc3 64"; do python profiles/phase_profile.py $k; done > "$out/phase_profile.jsonl" 2>> "$out/bench.err"
+for k in "mixed 16" "text 16" "runs 16" "bc3 64" "samples16 16" "records 16"; do python profiles/phase_profile.py $k; done > "$out/phase_profile.jsonl" 2>> "$out/bench.err"
+BROTLIG_ENCODER_FLAGS=192 python profiles/phase_profile.py mixed 4 >> "$out/phase_profile.jsonl" 2>> "$out/bench.err"      # the optimal-parse streams (`alt`), 4 streams: the encode is slow
+python profiles/tools/config5_projection.py --out "$out/config5_projection.json" > /dev/null 2>> "$out/bench.err"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o f -- python "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$out/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o f -- python "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1

@@ -9,7 +9,7 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 pre = os.path.join(dst, f"r{rnd}_{tag}_")
 
-for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16", "bench_records", "bench_distinct4096", "latency", "streamer_bench", "cpu_decode"):
+for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16", "bench_records", "bench_distinct4096", "latency", "streamer_bench", "cpu_decode", "config5_projection"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, pre + name + ".json")
