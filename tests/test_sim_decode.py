@@ -31,7 +31,9 @@ def build_sim(name, flags=()):
     deps = srcs + [os.path.join(SIM_DIR, f) for f in ("sim_runtime.h", "brotlig_wave_ops.h")] + \
         [os.path.join(CSRC, f) for f in ("brotlig_kernels.h", "experimental/brotlig_split_kernels.h", "brotlig_format.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DBROTLIG_WITH_SPLIT", "-I", SIM_DIR, "-I", CSRC, "-o", so] + list(flags) + srcs)
+        tmp = f"{so}.{os.getpid()}.tmp"             # built aside and moved into place: pytest-xdist workers may get here together
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DBROTLIG_WITH_SPLIT", "-I", SIM_DIR, "-I", CSRC, "-o", tmp] + list(flags) + srcs)
+        os.replace(tmp, so)
     L = ctypes.CDLL(so)
     L.sim_decode_batch.restype = ctypes.c_int
     L.sim_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
