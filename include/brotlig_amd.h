@@ -20,7 +20,8 @@ extern "C" {
 /* ABI version of the device-pointer batch interface.  Version 3 (round 3): 32-byte BrotligStreamDesc (was 16), d_in must
  * extend 16 bytes past in_bytes, the workspace holds the per-wavefront symbol slots (+30 MiB: 8192 workgroups).  The entry points whose
  * contract changed carry the version in their SYMBOL names (the macros below), so a caller built against an older header
- * fails to link instead of passing descriptors of the wrong stride; BrotligAbiVersion() answers at run time (dlopen users). */
+ * fails to link instead of passing descriptors of the wrong stride; BrotligAbiVersion() answers at run time (dlopen users).
+ * Round 4 only ADDED entry points (BrotligDecodeBatchMultiDeviceAsync / ...Wait): the version stays 3. */
 #define BROTLIG_AMD_ABI_VERSION 3
 #define BrotligDecodeWorkspaceSize      BrotligDecodeWorkspaceSize_v3
 #define BrotligDecodeWorkspaceSizeFor   BrotligDecodeWorkspaceSizeFor_v3
