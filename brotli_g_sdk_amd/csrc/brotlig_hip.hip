@@ -202,7 +202,13 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
         else hipLaunchKernelGGL(brotlig_assemble_kernel, dim3(g.assemble), dim3(64), 0, s, a);
     } else
 #endif
-    hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, s, a);
+    {   // a batch that cannot hold more pages than that needs no more wavefronts (every page is at least 32 KiB of the caller's output
+        // region): a single asset launches a handful of workgroups instead of 4 096.  (The kernel itself sends home every wavefront beyond
+        // the batch's page count before it touches the page counter -- that is what takes 45 us off a single page; round 4.)
+        const uint64_t bound = max_pages(a.num_streams, a.out_bytes);
+        const unsigned grid = bound < (uint64_t)g.decode ? (unsigned)(bound ? bound : 1u) : (unsigned)g.decode;
+        hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
+    }
     if (k1) HIP_OK(hipEventRecord(k1, s));
     {   // streams over y, each stream's tiles over x; about 8 workgroups of 256 per CU in total
         const unsigned gy = a.num_streams < 32u ? a.num_streams : 32u;

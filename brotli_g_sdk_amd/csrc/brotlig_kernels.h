@@ -2123,6 +2123,7 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
     // neighbour: every phase of a round costs the maximum over the two halves).  So the upper halves only take part in as many
     // wavefronts as there are pages beyond one per wavefront; from two pages per wavefront on, every half works.
     const uint32_t total0 = a.page_base[a.num_streams];
+    if (blockIdx.x >= total0) return;       // more wavefronts than pages: the surplus leaves before it takes a turn at the page counter
     const uint32_t doubles = total0 > gridDim.x ? total0 - gridDim.x : 0u;     // wavefronts that need both halves
     if (blockIdx.x >= doubles) decode_pages<kProf, true>(W, a, prof_lds);
     else decode_pages<kProf, false>(W, a, prof_lds);
