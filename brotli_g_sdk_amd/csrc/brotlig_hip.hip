@@ -190,7 +190,10 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
         hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g.order), dim3(64), 0, s, a);
         hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, s, a);
     }
-    hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, s, a);
+    // the pairing policy only matters when two pages can meet in a wavefront: a batch that cannot hold more pages than the grid has
+    // wavefronts (every page >= 32 KiB of the output region) decodes one page per wavefront, and its launch is one kernel shorter
+    const bool may_pair = max_pages(a.num_streams, a.out_bytes) > (uint64_t)g.decode;
+    if (may_pair) hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, s, a);
     if (diag_policy() >= 0)                             // diagnostics: pin the pairing policy (quarters of a page a free half waits)
         HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), diag_policy(), 1, s));
     if (k0) HIP_OK(hipEventRecord(k0, s));
@@ -210,7 +213,8 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
         hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
     }
     if (k1) HIP_OK(hipEventRecord(k1, s));
-    {   // streams over y, each stream's tiles over x; about 8 workgroups of 256 per CU in total
+    if (a.scratch != nullptr) {   // (without a scratch buffer no stream of the batch can be pre-conditioned: the prepare kernel rejects them)
+        // streams over y, each stream's tiles over x; about 8 workgroups of 256 per CU in total
         const unsigned gy = a.num_streams < 32u ? a.num_streams : 32u;
         const unsigned gx = ((unsigned)g.decond + gy - 1u) / gy;
         hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(gx, gy), dim3(256), 0, s, a);
