@@ -234,6 +234,14 @@ class MultiDeviceAsync:
         return results
 
 
+def DebugSetDecodeGrid(workgroups):
+    """BrotligDebugSetDecodeGrid (diagnostics): 0 = the normal launch rule."""
+    L = lib()
+    L.BrotligDebugSetDecodeGrid.restype = None
+    L.BrotligDebugSetDecodeGrid.argtypes = [ctypes.c_uint32]
+    L.BrotligDebugSetDecodeGrid(int(workgroups))
+
+
 def DeviceSelfTest():
     rc = lib().BrotligDeviceSelfTest()
     if rc != BROTLIG_OK:

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -76,6 +77,9 @@ struct Grids {
 int env_int_once(const char* name) { const char* e = getenv(name); return e ? atoi(e) : -1; }
 int diag_wg_per_cu() { static const int v = env_int_once("BROTLIG_WG_PER_CU"); return v; }
 int diag_policy() { static const int v = env_int_once("BROTLIG_POLICY"); return v; }
+// Diagnostics (tests): a fixed decode grid, so that a SMALL batch can be decoded two pages per wavefront (grid < pages / 2) as well as
+// one page per wavefront (the default for it).  0 = the normal rule.  Process-wide, not thread-safe: tests only.
+std::atomic<uint32_t> g_debug_grid{0};
 constexpr int kMaxDevices = 64;
 std::mutex g_grid_mutex;
 Grids g_grids[kMaxDevices];
@@ -192,7 +196,7 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     }
     // the pairing policy only matters when two pages can meet in a wavefront: a batch that cannot hold more pages than the grid has
     // wavefronts (every page >= 32 KiB of the output region) decodes one page per wavefront, and its launch is one kernel shorter
-    const bool may_pair = max_pages(a.num_streams, a.out_bytes) > (uint64_t)g.decode;
+    const bool may_pair = max_pages(a.num_streams, a.out_bytes) > (uint64_t)g.decode || g_debug_grid.load() != 0u;
     if (may_pair) hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, s, a);
     if (diag_policy() >= 0)                             // diagnostics: pin the pairing policy (quarters of a page a free half waits)
         HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), diag_policy(), 1, s));
@@ -209,7 +213,8 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
         // region): a single asset launches a handful of workgroups instead of 4 096.  (The kernel itself sends home every wavefront beyond
         // the batch's page count before it touches the page counter -- that is what takes 45 us off a single page; round 4.)
         const uint64_t bound = max_pages(a.num_streams, a.out_bytes);
-        const unsigned grid = bound < (uint64_t)g.decode ? (unsigned)(bound ? bound : 1u) : (unsigned)g.decode;
+        unsigned grid = bound < (uint64_t)g.decode ? (unsigned)(bound ? bound : 1u) : (unsigned)g.decode;
+        if (const uint32_t forced = g_debug_grid.load()) grid = forced < (unsigned)g.decode ? forced : (unsigned)g.decode;
         hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
     }
     if (k1) HIP_OK(hipEventRecord(k1, s));
@@ -626,6 +631,7 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     return BROTLIG_OK;
 }
 
+extern "C" void BrotligDebugSetDecodeGrid(uint32_t workgroups) { g_debug_grid.store(workgroups); }
 extern "C" uint32_t BrotligAbiVersion(void) { return BROTLIG_AMD_ABI_VERSION; }
 extern "C" uint32_t BrotligKernelLdsBytes(void) { return (uint32_t)sizeof(WaveLds); }
 extern "C" uint32_t BrotligKernelGridSize(void) { Grids g; return grid_sizes(&g) == BROTLIG_OK ? (uint32_t)g.decode : 0u; }

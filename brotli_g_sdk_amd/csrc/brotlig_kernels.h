@@ -158,7 +158,7 @@ constexpr uint32_t kAblate = BROTLIG_ABLATE;
 #endif
 #ifndef BROTLIG_TUNE_ROUND_MAX
 #define BROTLIG_TUNE_ROUND_MAX 640      // round 4: groups of 640 bytes (history 656, window 1344): mixed +1.7 %, records +6.6 %, text -0.6 %, samples16 +0.2 %
-#define BROTLIG_TUNE_WIN 1344
+#define BROTLIG_TUNE_WIN 1328      // (1 344 until the ring moved to LDS: 16 bytes per page)
 #define BROTLIG_TUNE_DIST_LUT_BITS 8
 #endif
 #ifndef BROTLIG_TUNE_EARLY_NEAR
@@ -194,6 +194,25 @@ constexpr uint32_t kRoundMax = BROTLIG_TUNE_ROUND_MAX;     // bytes assembled pe
 static_assert(kHist >= kRoundMax + 16u && kWin >= kHist + 16u + kRoundMax, "window: history + one group");
 constexpr uint32_t kStageBytes = kRoundMax + 8 * 32;    // far-copy staging: every copy rounded up to 8 bytes
 static_assert(kStageBytes >= kRoundMax + 64u, "the staging area also holds a group's literals, with slack for 8-byte reads");
+// The same four numbers as a type: the page loop, the LDS record and the stages that depend on them are templates over it.
+// GeoPair (the constants above) is the layout of a wavefront that decodes two pages, one record per half.  GeoSolo (round 4) is
+// the layout of a wavefront that decodes ONE page at a time (small batches: no more pages than wavefronts): it has the LDS of
+// both halves for one record, so its groups are 1 024 bytes -- the per-group work (flush, slide, piece classification, bitmaps,
+// level bookkeeping) is 30 % of a run-length page's time at 640 -- and its window keeps 4 KiB of history on chip.
+template <uint32_t kRM, uint32_t kH, uint32_t kW> struct Geometry {
+    static constexpr uint32_t kRoundMax = kRM, kHist = kH, kWin = kW, kStageBytes = kRM + 8 * 32;
+    static constexpr uint32_t kFlushPieces = (kRM + 16u + 511u) / 512u;     // 16-byte pieces per lane that a group's flush can need
+    static constexpr uint32_t kSlidePieces = (kH + 16u + 511u) / 512u;      // ... and the slide of the history
+    static_assert(kH >= kRM + 16u && kW >= kH + 16u + kRM && kRM % 32u == 0u && kRM <= 1024u, "window: history + one group; 32 bitmap words at most");
+    static_assert(kFlushPieces <= 3u && kSlidePieces <= 3u, "flush_and_slide moves up to three pieces per lane");
+};
+typedef Geometry<kRoundMax, kHist, kWin> GeoPair;
+#ifndef BROTLIG_TUNE_SOLO_ROUND_MAX
+#define BROTLIG_TUNE_SOLO_ROUND_MAX 1024
+#define BROTLIG_TUNE_SOLO_HIST 1040
+#define BROTLIG_TUNE_SOLO_WIN 5120
+#endif
+typedef Geometry<BROTLIG_TUNE_SOLO_ROUND_MAX, BROTLIG_TUNE_SOLO_HIST, BROTLIG_TUNE_SOLO_WIN> GeoSolo;
 
 // insert / copy length codes: base | extra_bits << 16   (RFC 7932 section 5; the reference carries
 // them as sBrotligCmdLut, inc/common/BrotligCommandLut.h:41-747, and the shader regenerates them
@@ -214,7 +233,8 @@ __device__ static const uint32_t kLenCodeTab[48] = {
 __device__ static const uint8_t kCodeLenOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
 
 // ---- LDS layout: one of these per 32-lane half ---------------------------------------------
-struct __attribute__((aligned(16))) PageLds {
+template <class G>
+struct __attribute__((aligned(16))) PageLdsT {
     // decode LUTs, then the staging area: while a table is being built its LUT and the 1 KiB behind it
     // serve as scratch (code-length LUT, counting-sort counters), so the order of these four matters --
     // ICP borrows the distance LUT, distance borrows the literal LUT, literal borrows the staging area,
@@ -222,7 +242,7 @@ struct __attribute__((aligned(16))) PageLds {
     uint16_t lut_icp[1 << kLutBitsIcp];
     uint16_t lut_dist[1 << kLutBitsDist];
     uint16_t lut_lit[1 << kLutBitsLit];
-    uint64_t stage[kStageBytes / 8];        // per group: first the group's literals in consumption order (they move to
+    uint64_t stage[G::kStageBytes / 8];     // per group: first the group's literals in consumption order (they move to
                                             // the window before the far sources arrive), then the source bytes of far
                                             // copies (older than the window)
     uint32_t sorted_icp[(kIcpSymCap + 2) / 3];         // symbols in canonical-code order, three 10-bit fields per word
@@ -230,28 +250,32 @@ struct __attribute__((aligned(16))) PageLds {
     uint32_t sorted_lit[kLitAlphabet / 4];             // literals fit a byte each: plain byte array
     uint16_t limit[3][16] __attribute__((aligned(16)));     // per code length: exclusive upper bound, left-justified to 15 bits
     uint32_t first_offs[3][16]; // per code length: first code (left-justified) | index of its first symbol in sorted_* << 16
-    uint32_t start_bits[kRoundMax / 32];    // per group: bit p set <=> a command's piece starts at group byte p
-    uint8_t  start_cum[kRoundMax / 32];     // per group: piece starts in earlier words of start_bits
+    uint32_t start_bits[G::kRoundMax / 32]; // per group: bit p set <=> a command's piece starts at group byte p
+    uint8_t  start_cum[G::kRoundMax / 32];  // per group: piece starts in earlier words of start_bits
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
     uint32_t page_params;           // NPOSTFIX | (NDIRECT << NPOSTFIX) << 8 | delta-coded flag << 16 of the page being decoded
     uint32_t ring_push[2][4] __attribute__((aligned(16)));  // the last four distances pushed in a round, most recent first (two rounds alternate)
-    uint8_t  win[kWin + 16] __attribute__((aligned(16)));   // output window; doubles as the code-length
-                                                             // scratch (728 B) while tables are built
+    uint32_t ring_state[4] __attribute__((aligned(16)));    // the distance ring as of the start of the previous round's pushes (resolve_distance_ring)
+    uint8_t  win[G::kWin + 16] __attribute__((aligned(16)));    // output window; doubles as the code-length
+                                                                 // scratch (728 B) while tables are built
 };
+typedef PageLdsT<GeoPair> PageLds;
+typedef PageLdsT<GeoSolo> PageLdsSolo;
 constexpr uint32_t kTableScratchBytes = 1024;   // 512-entry code-length LUT, or 16 x 32 counters, as uint16
 static_assert(sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)) >= kTableScratchBytes, "ICP build scratch");
 static_assert(sizeof(uint16_t) * ((1 << kLutBitsDist) + (1 << kLutBitsLit)) + kStageBytes >= kTableScratchBytes, "distance build scratch");
 static_assert(sizeof(uint16_t) * (1 << kLutBitsLit) + kStageBytes >= kTableScratchBytes, "literal build scratch");
 static_assert(__builtin_offsetof(PageLds, lut_dist) == sizeof(uint16_t) * (1 << kLutBitsIcp), "LUTs must be contiguous");
 static_assert(__builtin_offsetof(PageLds, stage) == sizeof(uint16_t) * ((1 << kLutBitsIcp) + (1 << kLutBitsDist) + (1 << kLutBitsLit)), "staging area must follow the LUTs");
-static_assert(kHist + 16u <= 1024u && kRoundMax + 16u <= 1024u && kRoundMax % 32u == 0u && kWin - kHist >= kRoundMax + 16u,
-              "the slide and the flush move at most two 16-byte pieces per lane; a group fits behind the history");
 static_assert(kWin + 16 >= kIcpAlphabet, "the window holds the code lengths during the table build");
 
 struct __attribute__((aligned(16))) WaveLds {
     PageLds  page[2];
     uint32_t len_code_tab[48];
 };
+// the one-page layout lives in the same storage (decode_kernel_body); len_code_tab stays where it is
+static_assert(sizeof(PageLdsSolo) <= 2 * sizeof(PageLds), "the one-page record must fit the LDS of the two halves");
+static_assert(__builtin_offsetof(PageLdsSolo, stage) == __builtin_offsetof(PageLds, stage), "same table-build scratch order in both layouts");
 
 __device__ __forceinline__ uint64_t load_u64u_g(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 // sixteen bytes at a 16-byte aligned address, kept in registers (one b128 access)
@@ -880,11 +904,15 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
 // below the window, i.e. more than kHist >= kRoundMax + 16 bytes back -- only ever reads global memory written by an
 // EARLIER group's flush.  When the group does not fit behind what the window holds, the window slides: kHist .. kHist + 15
 // bytes of history are kept and brought down in one step, all reads before the writes.
+template <class G = GeoPair>
 __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed, uint8_t* out, bool on, uint32_t gpos, uint32_t gend, uint32_t sl)
 {
-    const bool slide = on && gend > view.win_base + kWin && !(kAblate & kAblSlide);
+    const bool slide = on && gend > view.win_base + G::kWin && !(kAblate & kAblSlide);
     wave::sync();
-    {
+    // (the two-piece and the three-piece forms are written out separately: with the third piece as a folded-away branch inside
+    // the two-piece code the compiler dropped the skip branches around the second store and issued it with an empty mask --
+    // one global store and one load more per round, 4.7 % on the mixed data; round 4)
+    if constexpr (G::kFlushPieces <= 2u) {
         const uint32_t e16 = gpos & ~15u;
         const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
         const bool f0 = on && p0 < e16, f1 = on && p1 < e16;
@@ -894,17 +922,41 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
         if (f0) store16(out + p0, a0);
         if (f1) store16(out + p1, a1);
         if (on && e16 > flushed) flushed = e16;
+    } else {
+        const uint32_t e16 = gpos & ~15u;
+        const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u, p2 = p0 + 1024u;
+        const bool f0 = on && p0 < e16, f1 = on && p1 < e16, f2 = on && p2 < e16;
+        Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0, a2 = a0;
+        if (f0) a0 = load16(view.win + (p0 - view.win_base));
+        if (f1) a1 = load16(view.win + (p1 - view.win_base));
+        if (f2) a2 = load16(view.win + (p2 - view.win_base));
+        if (f0) store16(out + p0, a0);
+        if (f1) store16(out + p1, a1);
+        if (f2) store16(out + p2, a2);
+        if (on && e16 > flushed) flushed = e16;
     }
     if (wave::any(slide)) {
-        const uint32_t nb = slide ? (gpos - kHist) & ~15u : view.win_base;
+        const uint32_t nb = slide ? (gpos - G::kHist) & ~15u : view.win_base;
         const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
-        const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
-        Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0;
-        if (i0 < count) m0 = load16(view.win + shift + i0);
-        if (i1 < count) m1 = load16(view.win + shift + i1);
-        wave::sync();
-        if (i0 < count) store16(view.win + i0, m0);
-        if (i1 < count) store16(view.win + i1, m1);
+        if constexpr (G::kSlidePieces <= 2u) {
+            const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
+            Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0;
+            if (i0 < count) m0 = load16(view.win + shift + i0);
+            if (i1 < count) m1 = load16(view.win + shift + i1);
+            wave::sync();
+            if (i0 < count) store16(view.win + i0, m0);
+            if (i1 < count) store16(view.win + i1, m1);
+        } else {
+            const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl, i2 = 1024u + 16u * sl;
+            Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0, m2 = m0;
+            if (i0 < count) m0 = load16(view.win + shift + i0);
+            if (i1 < count) m1 = load16(view.win + shift + i1);
+            if (i2 < count) m2 = load16(view.win + shift + i2);
+            wave::sync();
+            if (i0 < count) store16(view.win + i0, m0);
+            if (i1 < count) store16(view.win + i1, m1);
+            if (i2 < count) store16(view.win + i2, m2);
+        }
         view.win_base = nb;
     }
     wave::sync();
@@ -1038,7 +1090,7 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
         } else {
         clk.count(kPhTeamLevels, 1);
         // Small batches (round 4): a wavefront that decodes one page lends the idle upper half to the teams -- twice the lanes
-        // per long piece.  The upper lanes address the lower half's LDS record (the two are adjacent in WaveLds) and take the
+        // per long piece.  All 64 lanes work in the one record of the wavefront (PageRecord<true>); the upper lanes take the
         // pieces' fields from the lower half's lanes.
         Team t;
         uint32_t t_pk, t_dist, t_src, t_dst, team_mask = ready_mask;
@@ -1050,8 +1102,6 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             t = make_team64(team_mask, lane);
             t_pk = wave::bcast(packed, t.job); t_dist = wave::bcast(dist, t.job);
             t_src = wave::bcast(src_idx, t.job); t_dst = wave::bcast(dst_idx, t.job);
-            const uint32_t back = lane >= 32u ? (uint32_t)sizeof(PageLds) : 0u;
-            t_lds = win - back; t_stg -= back;
         } else {
             t = make_team(ready_mask, sl);
             t_pk = wave::half_shfl(packed, t.job); t_dist = wave::half_shfl(dist, t.job);
@@ -1235,17 +1285,17 @@ __device__ __forceinline__ void store_far_sources(uint8_t* win, uint64_t* stage,
 // piece starts at group byte p) and the number of starts before each of its words answer "which piece owns byte x" with
 // one popcount.  Returns the lanes (of the half) whose pieces own bytes of [psrc, src_end) inside the group and come
 // before me; everything below the group (page position gpos) is final.
-template <class Clock>
+template <class Clock, class G = GeoPair>
 __device__ __forceinline__ uint32_t piece_dependencies(uint32_t* start_bits, uint8_t* start_cum, bool on, bool in_group, uint32_t first_rel, uint32_t gpos,
                                                         uint32_t psrc, uint32_t src_end, bool has_piece, uint32_t sl, Clock& clk)
 {
     const uint32_t piece_mask = wave::half_ballot(in_group);
-    if (on && sl < kRoundMax / 32u) start_bits[sl] = 0u;
+    if (on && sl < G::kRoundMax / 32u) start_bits[sl] = 0u;
     wave::sync();
     if (in_group) atomicOr(&start_bits[first_rel >> 5], 1u << (first_rel & 31u));
     wave::sync();
     {
-        const bool rd = on && sl < kRoundMax / 32u;
+        const bool rd = on && sl < G::kRoundMax / 32u;
         const uint32_t w = rd ? start_bits[sl] : 0u;
         const uint32_t cw = wave::half_scan_incl((uint32_t)__popc(w));
         if (rd) start_cum[sl] = (uint8_t)(cw - (uint32_t)__popc(w));
@@ -1286,7 +1336,7 @@ __device__ __forceinline__ TableRef table_of(Lds& L, uint32_t k, uint16_t* far_s
                     k == 0u ? kLutBitsIcp : k == 1u ? kLutBitsDist : kLutBitsLit, far_syms};
 }
 // fused kernel: the output window holds the code lengths of whichever table is being built
-__device__ __forceinline__ uint8_t* build_lens(PageLds& L, uint32_t) { return L.win; }
+template <class G> __device__ __forceinline__ uint8_t* build_lens(PageLdsT<G>& L, uint32_t) { return L.win; }
 
 // ---- stage: page start.  The halves with `want` take pages from the work counter until each holds a compressed one
 // (stored pages, PageDecoder.cpp:70-76, are copied on the spot; rejected ones skipped), then read the page header and
@@ -1425,30 +1475,47 @@ __device__ __forceinline__ RoundCommands decode_round_commands(const Lds& L, con
 
 // ---- stage: the distance ring (PageDecoder.cpp:345-364, :396-403).  The ring proper lives in registers; the last four
 // distances pushed in a round travel to the next round through LDS (ring_push, two rounds alternate).
+// Round 4: the ring itself lives in LDS between rounds (Lds::ring_state, four words), not in registers: its four values are only
+// needed inside resolve_distance_ring, and four registers live across a whole round were what the register allocator paid for
+// with a scratch store and reload per round whenever the rest of the kernel changed a little (-4.7 % when it happened).
 struct DistanceRing {
-    uint32_t r0 = 4, r1 = 11, r2 = 15, r3 = 16;     // PageDecoder.cpp:150-153
     uint32_t cnt = 0, par = 0;                      // pushes of the previous round still to be folded in, and where they are
-    __device__ __forceinline__ void reset() { r0 = 4; r1 = 11; r2 = 15; r3 = 16; cnt = 0; }
+    template <class Lds> __device__ __forceinline__ void reset(Lds& L, bool starting, uint32_t sl)
+    {
+        // 4, 11, 15, 16 (PageDecoder.cpp:150-153), one word per lane out of a packed constant: written as four constants the compiler
+        // builds a constant vector, keeps it in four registers for the whole kernel, spills it and reloads it in every round
+        if (starting && sl < 4u) L.ring_state[sl] = (0x100F0B04u >> (8u * sl)) & 0xFFu;
+        if (starting) cnt = 0;
+    }
 };
-// the previous round's pushes: read at the top of a round, folded in by resolve_distance_ring
+struct RingWords { Bytes16 pushed, state; };
+// the ring and the previous round's pushes: read at the top of a round, folded together by resolve_distance_ring
 template <class Lds>
-__device__ __forceinline__ Bytes16 load_ring_pushes(const Lds& L, const DistanceRing& ring)
+__device__ __forceinline__ RingWords load_ring_pushes(const Lds& L, const DistanceRing& ring)
 {
-    Bytes16 pushed = {0u, 0u, 0u, 0u};
-    if (ring.cnt) pushed = *reinterpret_cast<const Bytes16*>(L.ring_push[ring.par ^ 1u]);
-    return pushed;
+    RingWords w;
+    w.pushed = Bytes16{0u, 0u, 0u, 0u};
+    w.state = *reinterpret_cast<const Bytes16*>(L.ring_state);
+    if (ring.cnt) w.pushed = *reinterpret_cast<const Bytes16*>(L.ring_push[ring.par ^ 1u]);
+    return w;
 }
 // Codes 1..15 are resolved in command order; explicit distances and code 0 need no serial step.  On return c.dist
 // is final for every copy command of the round.
 template <class Lds>
-__device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring, Bytes16 pushed, RoundCommands& c, uint32_t sl)
+__device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring, const RingWords& w, RoundCommands& c, uint32_t sl)
 {
+    uint32_t r0 = w.state[0], r1 = w.state[1], r2 = w.state[2], r3 = w.state[3];
     {   // new ring = the last four pushed distances (PageDecoder.cpp:396-403)
-        const uint32_t o0 = ring.r0, o1 = ring.r1, o2 = ring.r2;
-        if (ring.cnt >= 4u) { ring.r0 = pushed[0]; ring.r1 = pushed[1]; ring.r2 = pushed[2]; ring.r3 = pushed[3]; }
-        else if (ring.cnt == 3u) { ring.r0 = pushed[0]; ring.r1 = pushed[1]; ring.r2 = pushed[2]; ring.r3 = o0; }
-        else if (ring.cnt == 2u) { ring.r0 = pushed[0]; ring.r1 = pushed[1]; ring.r2 = o0; ring.r3 = o1; }
-        else if (ring.cnt == 1u) { ring.r0 = pushed[0]; ring.r1 = o0; ring.r2 = o1; ring.r3 = o2; }
+        const Bytes16& pushed = w.pushed;
+        const uint32_t o0 = r0, o1 = r1, o2 = r2;
+        if (ring.cnt >= 4u) { r0 = pushed[0]; r1 = pushed[1]; r2 = pushed[2]; r3 = pushed[3]; }
+        else if (ring.cnt == 3u) { r0 = pushed[0]; r1 = pushed[1]; r2 = pushed[2]; r3 = o0; }
+        else if (ring.cnt == 2u) { r0 = pushed[0]; r1 = pushed[1]; r2 = o0; r3 = o1; }
+        else if (ring.cnt == 1u) { r0 = pushed[0]; r1 = o0; r2 = o1; r3 = o2; }
+        if (ring.cnt != 0u && sl == 0u) {                           // (every lane of the half has read the old words: LDS accesses execute in order)
+            const Bytes16 next = {r0, r1, r2, r3};
+            *reinterpret_cast<Bytes16*>(L.ring_state) = next;
+        }
     }
     const uint32_t dcode = c.dcode;
     uint32_t dist = c.dist;
@@ -1469,7 +1536,7 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
         const bool from_round = r < cnt;                            // else: carried ring entry r - cnt
         const uint32_t src = from_round ? msb_u32(below) : 0u;
         const uint32_t q = r - cnt;
-        const uint32_t carried = q == 0u ? ring.r0 : q == 1u ? ring.r1 : q == 2u ? ring.r2 : ring.r3;
+        const uint32_t carried = q == 0u ? r0 : q == 1u ? r1 : q == 2u ? r2 : r3;
         const uint32_t j = dcode >= 4u ? (dcode - 4u) % 6u : 0u, mag = dcode >= 4u ? (j >> 1) + 1u : 0u;
         while (wave::any(pend != 0u)) {
             const bool mine = ((pend >> sl) & 1u) != 0u;
@@ -1485,7 +1552,7 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
     {
         const uint32_t below = push_mask & ((1u << sl) - 1u);
         const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
-        if (is_copy && dcode == 0u) dist = below ? from : ring.r0;
+        if (is_copy && dcode == 0u) dist = below ? from : r0;
         // the round's last four pushes go to LDS, most recent first; the next round folds them into the ring
         const bool pusher = is_copy && dcode != 0u;
         const uint32_t above = (uint32_t)__popc((push_mask >> sl) >> 1);    // pushes after mine
@@ -1503,14 +1570,27 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
 // stays uniform: one iteration = (page start for the halves that need one) + (one round for the
 // halves inside a page) + (page end for the halves whose page just finished), each under per-half
 // predicates.
+// which LDS record a lane works in, and with which geometry: a record per half, or (one page per wavefront) one record for the whole
+// wavefront in the storage of both -- the upper half has no page of its own and never writes to it except as a member of a copy team
+template <bool kSolo> struct PageRecord;
+template <> struct PageRecord<false> {
+    typedef GeoPair G;
+    static __device__ __forceinline__ PageLds& of(WaveLds& W, uint32_t lane) { return W.page[lane >> 5]; }
+};
+template <> struct PageRecord<true> {
+    typedef GeoSolo G;
+    static __device__ __forceinline__ PageLdsSolo& of(WaveLds& W, uint32_t) { return *reinterpret_cast<PageLdsSolo*>(&W.page[0]); }
+};
+
 template <bool kProf, bool kSolo>
 __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned long long* prof_lds)
 {
+    typedef typename PageRecord<kSolo>::G G;
     PhaseClock<kProf> clk;
     clk.start(prof_lds);
     const uint32_t lane = wave::lane_id();
     const uint32_t sl = lane & 31u;
-    PageLds& L = W.page[lane >> 5];
+    PageLdsT<G>& L = PageRecord<kSolo>::of(W, lane);
 
     // the three prefix codes of a page: ICP, distance, literal (PageDecoder.cpp:125-147)
     uint16_t* const far_syms = a.far_syms + (size_t)blockIdx.x * (2u * kFarSymStride);
@@ -1551,8 +1631,8 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
                 clk.lap(kPhDelta);
                 bool tables_ok = true;
                 const bool start = start_pages(a, L, job, br, want, finished, sl, far_syms, tables_ok, [](const PageJob&) {}, clk);
+                ring.reset(L, start, sl);
                 if (start) {
-                    ring.reset();
                     out_pos = 0; prev_tail = 0; carry_head = 0; flushed = 0; bad = false;
                     view.win_base = 0u;
                     live = true;
@@ -1569,7 +1649,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
         // ---- rounds (PageDecoder.cpp:174-236; format A.6) until a page ends
         do {
         // -- 1. one command per lane (the previous round's ring pushes are requested first: they are needed in step 2)
-        const Bytes16 pushed = load_ring_pushes(L, ring);
+        const RingWords pushed = load_ring_pushes(L, ring);
         RoundCommands cmd = decode_round_commands(L, W.len_code_tab, t_icp, t_dist, br, live, sl, clk);
         const uint32_t sent_mask = cmd.sent_mask, n = cmd.n;
         const bool is_cmd = cmd.is_cmd;
@@ -1613,15 +1693,15 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
         // kRoundMax bytes -- nearly always a single group.  A command that crosses a group boundary
         // contributes a piece to each group; a copy piece past the first is an ordinary copy from
         // `dist` bytes back (its earlier bytes are final by then).
-        const uint32_t ngroups = live ? (round_bytes + kRoundMax - 1u) / kRoundMax : 0u;
+        const uint32_t ngroups = live ? (round_bytes + G::kRoundMax - 1u) / G::kRoundMax : 0u;
         const bool multi_group = wave::any(ngroups > 1u);
         for (uint32_t g = 0; wave::any(g < ngroups); ++g) {
             const bool on = g < ngroups;
-            const uint32_t g0 = g * kRoundMax, g1 = on ? min_u32(round_bytes, g0 + kRoundMax) : g0;
+            const uint32_t g0 = g * G::kRoundMax, g1 = on ? min_u32(round_bytes, g0 + G::kRoundMax) : g0;
             const uint32_t gpos = out_pos + g0;                         // page position of the group's first byte
 
             // -- 3b. flush the finished bytes, slide the window when the group does not fit
-            flush_and_slide(view, flushed, job.out, on, gpos, out_pos + g1, sl);
+            flush_and_slide<G>(view, flushed, job.out, on, gpos, out_pos + g1, sl);
             clk.lap(kPhSlide);
             clk.count(kPhGroups, 1);
             clk.halves(kPhGroupHalves, on);
@@ -1665,7 +1745,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             if (multi_group) { F0 = wave::half_sum(mine_before); F1 = F0 + wave::half_sum(nlit); }
             // exact dependencies of my copy piece: the pieces (of commands before me) that own bytes of its source range
             // inside this group; everything below the group is final
-            const uint32_t dep_mask = piece_dependencies(L.start_bits, L.start_cum, on, in_group, (rel0 > g0 ? rel0 : g0) - g0, gpos,
+            const uint32_t dep_mask = piece_dependencies<PhaseClock<kProf>, G>(L.start_bits, L.start_cum, on, in_group, (rel0 > g0 ? rel0 : g0) - g0, gpos,
                                                          psrc, src_end, plen != 0u && !far_direct && !(kAblate & kAblDeps), sl, clk);
             clk.lap(kPhCopyFence);
 

@@ -59,6 +59,7 @@ struct __attribute__((aligned(16))) EntropyLds {       // one per 32-lane half
     uint32_t first_offs[3][16];
     uint32_t page_params;
     uint32_t ring_push[2][4] __attribute__((aligned(16)));
+    uint32_t ring_state[4] __attribute__((aligned(16)));
 };
 static_assert(kLutBitsIcp == 8 && kLutBitsDist == 8 && kLutBitsLit == 8, "build areas are laid out for three 512-byte LUTs");
 static_assert(__builtin_offsetof(EntropyLds, build_tail) == 1536 && __builtin_offsetof(EntropyLds, lit_lens) == 1536 + 544, "build areas must follow the LUTs");
@@ -196,8 +197,8 @@ __device__ inline void entropy_pages(EntropyWaveLds& W, const DecodeArgs& a)
                 const bool start = start_pages(a, L, job, br, want, finished, sl, far_syms, tables_ok,
                                                [slot_hdr, sl](const PageJob& j) { if (sl == 0u) slot_hdr[2u * j.index + 1u] = 0u; },   // nothing for the assembly kernel (yet)
                                                clk);
+                ring.reset(L, start, sl);
                 if (start) {
-                    ring.reset();
                     out_pos = 0; lit_pos = 0; prev_tail = 0; cmd_count = 0; bad = false;
                     live = true;
                     if (!tables_ok) { bad = true; out_pos = job.out_size; }     // first round is refused (or a bare sentinel)
@@ -211,7 +212,7 @@ __device__ inline void entropy_pages(EntropyWaveLds& W, const DecodeArgs& a)
 
         do {
         // -- 1. one command per lane, 2. the distance ring (stages shared with the fused kernel)
-        const Bytes16 pushed = load_ring_pushes(L, ring);
+        const RingWords pushed = load_ring_pushes(L, ring);
         RoundCommands cmd = decode_round_commands(L, W.len_code_tab, t_icp, t_dist, br, live, sl, clk);
         resolve_distance_ring(L, ring, pushed, cmd, sl);
         const uint32_t sent_mask = cmd.sent_mask, n = cmd.n, ins = cmd.ins, copy = cmd.copy, dist = cmd.dist;

@@ -228,6 +228,11 @@ BROTLIG_ERROR BrotligStreamerSubmit(BrotligStreamer* streamer, uint32_t num_stre
 BROTLIG_ERROR BrotligStreamerWait(BrotligStreamer* streamer, uint64_t ticket);
 const uint8_t* BrotligStreamerOutput(BrotligStreamer* streamer, uint64_t ticket, uint32_t index, uint32_t* size);
 
+/* Diagnostics, for tests: decode with exactly `workgroups` wavefronts (0 = the normal rule: one per page while the batch has no more
+ * pages than the device holds wavefronts, the full grid otherwise), so that a small batch can exercise the two-pages-per-wavefront
+ * path as well as the one-page path it gets by default.  Process-wide. */
+void BrotligDebugSetDecodeGrid(uint32_t workgroups);
+
 /* Static properties, for reports: LDS bytes per workgroup, workgroups launched. */
 uint32_t BrotligKernelLdsBytes(void);
 uint32_t BrotligKernelGridSize(void);

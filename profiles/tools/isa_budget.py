@@ -208,6 +208,21 @@ def main():
             fn, f, ln = st[0]
             line_detail[(fn.split("<")[0], ln)][cls] += 1
 
+    # Scratch accesses inside the round loops, from the build WITHOUT -g (the one that ships): -g moves the register allocation, and
+    # a spill inside a round (one scratch round trip per round: 4-5 % of the kernel when it happened in round 4) does not show in the
+    # -g listing.  Round loops = natural loops of 1 500 .. 4 000 instructions (one per instantiation of the page loop).
+    insts_n = disassemble(co_n, kernel_symbol(co_n, a.kernel)[0])
+    start_n = kernel_symbol(co_n, a.kernel)[1]
+    round_loops = set()
+    for i in insts_n:
+        if i["op"].startswith(("s_cbranch", "s_branch")) and i["label"] is not None and start_n + i["label"] <= i["addr"]:
+            round_loops.add((start_n + i["label"], i["addr"]))
+    spills_in_rounds = []
+    for lo, hi in sorted(round_loops):
+        n = sum(1 for i in insts_n if lo <= i["addr"] <= hi)
+        if 1500 <= n <= 4000:
+            sc = [(hex(i["addr"] - start_n), i["op"]) for i in insts_n if lo <= i["addr"] <= hi and i["op"].startswith("scratch_")]
+            spills_in_rounds.append((hex(lo - start_n), hex(hi - start_n), n, sc))
     classes = ["VALU", "SALU", "BRANCH", "WAIT", "LDS", "VMEM", "SCRATCH", "SMEM", "OTHER"]
     print(f"kernel {sym}: {len(insts)} instructions, {size} bytes (-g) / {size_n} bytes (no -g){'' if same else '  ** SIZES DIFFER: -g changed the code **'}")
     print(f"{'stage':36s} " + " ".join(f"{c:>7s}" for c in classes) + "   total")
@@ -218,6 +233,12 @@ def main():
         print(f"{s:36s} " + " ".join(f"{c[k]:7d}" for k in classes) + f"  {sum(c.values()):6d}")
         tot.update(c)
     print(f"{'TOTAL':36s} " + " ".join(f"{tot[k]:7d}" for k in classes) + f"  {sum(tot.values()):6d}")
+    print("\nscratch accesses inside round-sized loops of the build without -g (must be none):")
+    seen = set()
+    for lo, hi, n, sc in spills_in_rounds:
+        if not any(abs(int(lo, 16) - int(l2, 16)) < 64 for l2 in seen) or sc:
+            print(f"  loop {lo}-{hi} ({n} instructions): {len(sc)} {sc if sc else ''}")
+        seen.add(lo)
     if a.blocks:
         print("\nloops (innermost attribution; address range, back-edge source):")
         for key in sorted(per_loop):

@@ -92,7 +92,10 @@ def raw_stress_cases():
                                                (528, 536, 16, 16), (1000, 1100, 8, 120),
                                                # round 4: groups of 640 bytes, 656 bytes of history
                                                (641, 700, 8, 24), (657, 672, 4, 28), (657, 1400, 8, 24), (648, 668, 1, 63),
-                                               (656, 664, 16, 16)]):
+                                               (656, 664, 16, 16),
+                                               # round 4, one page per wavefront: groups of 1 024 bytes, 1 040 bytes of history, 5 120-byte window
+                                               # (a source between 1 040 and ~4 100 bytes back is in the window or not depending on the last slide)
+                                               (1025, 1100, 8, 24), (1041, 1056, 4, 28), (1030, 1050, 1, 63), (3900, 5300, 8, 56), (5100, 5200, 16, 120)]):
         for page in (65536, 131072):
             out.append((f"far_{dlo}_{dhi}_{lit}_{cpy}_{page >> 10}k",
                         (lambda a=dlo, b=dhi, l=lit, c=cpy, s=k: far_boundary(4 * 131072 + 777, 40 + s, a, b, l, c)),

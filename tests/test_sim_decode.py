@@ -125,6 +125,16 @@ def test_sim_one_page_per_wavefront_lends_the_upper_half_to_the_teams(sim):
             assert np.array_equal(o, d), grid
 
 
+@pytest.mark.parametrize("name,thunk,kw", [c for c in raw_stress_cases() if c[0].endswith("64k")][-7:], ids=lambda v: v if isinstance(v, str) else "")
+def test_sim_far_boundaries_one_page_per_wavefront(sim, name, thunk, kw):
+    """The far / near boundary of the ONE-page layout (groups of 1 024 bytes, 1 040 bytes of history, a 5 120-byte window): sources just
+    beyond the history, and sources that are in the window or not depending on when it last slid; as many wavefronts as pages."""
+    data = thunk()[:3 * 65536 + 999]
+    stream = E.encode(data, **kw)
+    outs, status = run_batch(sim, [stream], [len(data)], grid=4)
+    assert status == 0 and np.array_equal(outs[0], data)
+
+
 def test_sim_bad_header_sets_status(sim):
     s = E.encode(D.text(70000, 1)); s[1] ^= 1
     outs, status = run_batch(sim, [s], [70000])
