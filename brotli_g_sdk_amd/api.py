@@ -62,6 +62,7 @@ def lib():
     """Loads libbrotlig_hip.so (building it in-tree with hipcc if needed).  Raises if absent."""
     global _lib
     if _lib is None:
+        import torch  # noqa: F401  -- torch's copy of the HIP runtime must be the one in the process: loaded after this library it sees no device
         L = _Lib(ctypes.CDLL(_build.build_hip()))
         L.BrotligAbiVersion.restype = ctypes.c_uint32
         if L.BrotligAbiVersion() != ABI_VERSION:
@@ -240,6 +241,14 @@ def DebugSetDecodeGrid(workgroups):
     L.BrotligDebugSetDecodeGrid.restype = None
     L.BrotligDebugSetDecodeGrid.argtypes = [ctypes.c_uint32]
     L.BrotligDebugSetDecodeGrid(int(workgroups))
+
+
+def DebugSetDecodeMode(mode):
+    """BrotligDebugSetDecodeMode (diagnostics): 0 = the normal rule, 1 = never two wavefronts per page, 2 = always."""
+    L = lib()
+    L.BrotligDebugSetDecodeMode.restype = None
+    L.BrotligDebugSetDecodeMode.argtypes = [ctypes.c_uint32]
+    L.BrotligDebugSetDecodeMode(int(mode))
 
 
 def DeviceSelfTest():

@@ -43,6 +43,9 @@ size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 
 // per-half slots for the prefix-code symbols that overflow the LDS arrays, for every workgroup of the largest decode grid
 // (8192 workgroups x 2 halves x kFarSymStride uint16 = 30 MiB: the size brotlig_amd.h documents for the workspace)
 constexpr uint32_t kMaxDecodeGrid = 8192;
+#ifndef BROTLIG_DUO_MAX_PAGES
+#define BROTLIG_DUO_MAX_PAGES 1024
+#endif
 constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
 size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
 size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
@@ -67,7 +70,7 @@ constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
 // Launch geometry per device (CU count x occupancy of the decode kernel), looked up once per device;
 // host threads driving different devices (or the same one) may arrive here concurrently.
 struct Grids {
-    int decode = 0, decond = 1024, order = 1024;
+    int decode = 0, decond = 1024, order = 1024, duo = 512;
 #ifdef BROTLIG_WITH_SPLIT
     int entropy = 0, assemble = 0, assemble_global = 0, assemble_page = 0;
 #endif
@@ -80,6 +83,12 @@ int diag_policy() { static const int v = env_int_once("BROTLIG_POLICY"); return 
 // Diagnostics (tests): a fixed decode grid, so that a SMALL batch can be decoded two pages per wavefront (grid < pages / 2) as well as
 // one page per wavefront (the default for it).  0 = the normal rule.  Process-wide, not thread-safe: tests only.
 std::atomic<uint32_t> g_debug_grid{0};
+// Diagnostics (tests, profiles/tools/latency.py): 0 = the normal rule, 1 = never the two-wavefronts-per-page kernel, 2 = always.
+std::atomic<uint32_t> g_debug_mode{0};
+// Batches that cannot hold more pages than this (every page >= 32 KiB of the caller's output region) are decoded two wavefronts per
+// page (brotlig_decode_duo_kernel): the machine has four SIMDs per compute unit and a page alone keeps one of them busy.
+constexpr uint64_t kDuoMaxPages = BROTLIG_DUO_MAX_PAGES;
+constexpr int kDuoPerCu = 4;            // workgroups of two wavefronts per compute unit at most (one wavefront per SIMD at two)
 constexpr int kMaxDevices = 64;
 std::mutex g_grid_mutex;
 Grids g_grids[kMaxDevices];
@@ -103,6 +112,7 @@ BROTLIG_ERROR grid_sizes(Grids* out)
         if (diag_wg_per_cu() > 0) per_cu = diag_wg_per_cu();
         if (per_cu < 1) per_cu = 1;
         g.decond = cus * 8;
+        g.duo = cus * kDuoPerCu;
         g.order = cus * 4;
         g.decode = cus * per_cu < (int)kMaxDecodeGrid ? cus * per_cu : (int)kMaxDecodeGrid;
 #ifdef BROTLIG_WITH_SPLIT
@@ -213,9 +223,16 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
         // region): a single asset launches a handful of workgroups instead of 4 096.  (The kernel itself sends home every wavefront beyond
         // the batch's page count before it touches the page counter -- that is what takes 45 us off a single page; round 4.)
         const uint64_t bound = max_pages(a.num_streams, a.out_bytes);
-        unsigned grid = bound < (uint64_t)g.decode ? (unsigned)(bound ? bound : 1u) : (unsigned)g.decode;
-        if (const uint32_t forced = g_debug_grid.load()) grid = forced < (unsigned)g.decode ? forced : (unsigned)g.decode;
-        hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
+        const uint32_t mode = g_debug_mode.load(), forced = g_debug_grid.load();
+        if (mode == 2u || (mode == 0u && forced == 0u && bound <= kDuoMaxPages)) {
+            // few pages: two wavefronts per page, entropy decode and assembly a group apart (brotlig_kernels.h, duo_producer / duo_consumer)
+            const unsigned grid = bound < (uint64_t)g.duo ? (unsigned)(bound ? bound : 1u) : (unsigned)g.duo;
+            hipLaunchKernelGGL(brotlig_decode_duo_kernel, dim3(grid), dim3(128), 0, s, a);
+        } else {
+            unsigned grid = bound < (uint64_t)g.decode ? (unsigned)(bound ? bound : 1u) : (unsigned)g.decode;
+            if (forced) grid = forced < (unsigned)g.decode ? forced : (unsigned)g.decode;
+            hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
+        }
     }
     if (k1) HIP_OK(hipEventRecord(k1, s));
     if (a.scratch != nullptr) {   // (without a scratch buffer no stream of the batch can be pre-conditioned: the prepare kernel rejects them)
@@ -632,6 +649,7 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
 }
 
 extern "C" void BrotligDebugSetDecodeGrid(uint32_t workgroups) { g_debug_grid.store(workgroups); }
+extern "C" void BrotligDebugSetDecodeMode(uint32_t mode) { g_debug_mode.store(mode); }
 extern "C" uint32_t BrotligAbiVersion(void) { return BROTLIG_AMD_ABI_VERSION; }
 extern "C" uint32_t BrotligKernelLdsBytes(void) { return (uint32_t)sizeof(WaveLds); }
 extern "C" uint32_t BrotligKernelGridSize(void) { Grids g; return grid_sizes(&g) == BROTLIG_OK ? (uint32_t)g.decode : 0u; }

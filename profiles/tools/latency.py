@@ -5,8 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 from brotli_g_sdk_amd import api, datagen as D, encoder as E
 out = {}
-for kind in ("runs", "mixed"):
-    for pages in (1, 8, 64, 512, 4096):
+MODES = {"auto": 0, "one_wavefront": 1, "two_wavefronts": 2}
+modes = [m for m in sys.argv[1:] if m in MODES] or ["auto"]
+for mode in modes:
+  api.DebugSetDecodeMode(MODES[mode])
+  tag = "" if mode == "auto" else "_" + mode
+  for kind in ("runs", "mixed"):
+    for pages in (1, 8, 64, 512, 1024, 2048, 4096):
         base = (D.runs if kind == "runs" else D.mixed)(min(pages, 256) * 65536, 1)
         s = E.encode(base)
         if pages > 256: s = D.tile_stream(s, pages // 256)
@@ -14,7 +19,8 @@ for kind in ("runs", "mixed"):
         dec.decode()
         tot, k = dec.timed(3, 20)
         assert np.array_equal(dec.output(0)[:len(base)], base)
-        out[f"{kind}_{pages}"] = {"kernel_ms": round(k, 4), "GBps": round(pages * 65536 / k / 1e6, 1)}
+        out[f"{kind}_{pages}{tag}"] = {"kernel_ms": round(k, 4), "GBps": round(pages * 65536 / k / 1e6, 1)}
+api.DebugSetDecodeMode(0)
 # single assets through the host-pointer entry: DecodeGPU (a context per call: allocations) against a reusable BrotligContext
 import time
 ctx = api.Context()

@@ -50,3 +50,14 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
 def oracle():
     from helpers import oracle_lib
     return oracle_lib()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _decode_mode_from_env():
+    """BROTLIG_TEST_DECODE_MODE=1|2 runs the gpu-marked suite with the decode kernel pinned (BrotligDebugSetDecodeMode: 1 = one
+    wavefront per one or two pages for every batch, 2 = two wavefronts per page for every batch) instead of the size rule."""
+    mode = int(os.environ.get("BROTLIG_TEST_DECODE_MODE", "0"))
+    if mode and _hip_device_usable():
+        from brotli_g_sdk_amd import api
+        api.DebugSetDecodeMode(mode)
+    yield

@@ -17,6 +17,11 @@ static void order_count_body(void* p) { brotlig_order_count_kernel(*(DecodeArgs*
 static void order_scatter_body(void* p) { brotlig_order_scatter_kernel(*(DecodeArgs*)p); }
 static void policy_body(void* p) { brotlig_policy_kernel(*(DecodeArgs*)p); }
 static void decode_body(void* p) { brotlig_decode_kernel(*(DecodeArgs*)p); }
+static void duo_body(void* p) { brotlig_decode_duo_kernel(*(DecodeArgs*)p); }
+static int g_duo = 0;          // small-batch form: two wavefronts per page (brotlig_decode_duo_kernel)
+static uint64_t g_duo_launches = 0;
+extern "C" void sim_set_duo(int on) { g_duo = on; }
+extern "C" uint64_t sim_duo_launches() { return g_duo_launches; }
 static void decond_body(void* p) { brotlig_decondition_kernel(*(DecodeArgs*)p); }
 static void selftest_body(void* p) { brotlig_selftest_kernel((uint32_t*)p); }
 
@@ -46,7 +51,8 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     sim::run_grid(1, prepare_body, &a);
     if (a.order) { sim::run_grid(3, order_count_body, &a); sim::run_grid(3, order_scatter_body, &a); }
     sim::run_grid(1, policy_body, &a);
-    sim::run_grid(decode_grid, decode_body, &a);
+    if (g_duo) { ++g_duo_launches; sim::run_grid(decode_grid, duo_body, &a, 2); }
+    else sim::run_grid(decode_grid, decode_body, &a);
     sim::run_grid(3, decond_body, &a);
     *status_out = status_words[0];
     g_last_policy = status_words[3];

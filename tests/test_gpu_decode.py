@@ -62,18 +62,21 @@ def test_far_copies_read_what_the_previous_group_flushed(api, name, thunk, kw):
     rc, ref = oracle_decode(stream)
     assert rc == 0 and np.array_equal(ref, data)
     dec = api.BatchDecoder([stream] * 4)
-    # a batch this small decodes one page per wavefront (its own instantiation of the page loop, with its own group / window geometry);
-    # the second pass forces three wavefronts, so that the same pages also go two to a wavefront like those of a large batch
-    for grid in (0, 3):
+    # a batch this small is decoded two wavefronts per page (brotlig_decode_duo_kernel); the second pass takes the one-wavefront kernel
+    # with one page per wavefront (its own instantiation of the page loop, with its own group / window geometry), the third forces
+    # three wavefronts, so that the same pages also go two to a wavefront like those of a large batch
+    for mode, grid in ((0, 0), (1, 0), (1, 3)):
+        api.DebugSetDecodeMode(mode)
         api.DebugSetDecodeGrid(grid)
         try:
             for _ in range(3 if grid == 0 else 2):
                 dec.poison_output()
                 dec.decode()
                 for i in range(4):
-                    assert np.array_equal(dec.output(i), ref), (name, i, grid)
+                    assert np.array_equal(dec.output(i), ref), (name, i, mode, grid)
         finally:
             api.DebugSetDecodeGrid(0)
+            api.DebugSetDecodeMode(0)
 
 
 @pytest.mark.parametrize("name,thunk,kw", symbol_overflow_cases(), ids=[c[0] for c in symbol_overflow_cases()])

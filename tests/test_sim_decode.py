@@ -39,6 +39,8 @@ def build_sim(name, flags=()):
     L.sim_decode_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     L.sim_selftest.argtypes = [ctypes.c_void_p]
+    # BROTLIG_SIM_DUO=1: every launch of the suite through the two-wavefronts-per-page kernel (tests/test_sim_duo.py runs its own set)
+    L.sim_set_duo(1 if os.environ.get("BROTLIG_SIM_DUO", "0") == "1" else 0)
     return L
 
 
