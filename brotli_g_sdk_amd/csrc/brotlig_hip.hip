@@ -44,7 +44,7 @@ size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 
 // (8192 workgroups x 2 halves x kFarSymStride uint16 = 30 MiB: the size brotlig_amd.h documents for the workspace)
 constexpr uint32_t kMaxDecodeGrid = 8192;
 #ifndef BROTLIG_DUO_MAX_PAGES
-#define BROTLIG_DUO_MAX_PAGES 1024
+#define BROTLIG_DUO_MAX_PAGES 2048
 #endif
 constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
 size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
@@ -88,7 +88,11 @@ std::atomic<uint32_t> g_debug_mode{0};
 // Batches that cannot hold more pages than this (every page >= 32 KiB of the caller's output region) are decoded two wavefronts per
 // page (brotlig_decode_duo_kernel): the machine has four SIMDs per compute unit and a page alone keeps one of them busy.
 constexpr uint64_t kDuoMaxPages = BROTLIG_DUO_MAX_PAGES;
-constexpr int kDuoPerCu = 4;            // workgroups of two wavefronts per compute unit at most (one wavefront per SIMD at two)
+#ifndef BROTLIG_DUO_PER_CU
+#define BROTLIG_DUO_PER_CU 8
+#endif
+constexpr int kDuoPerCu = BROTLIG_DUO_PER_CU;            // workgroups of two wavefronts per compute unit at most (one wavefront per SIMD at two, the kernel's four at eight;
+                                        // measured with 4 / 8: 2 048 mixed pages 1.59 / 1.06 ms, against 1.33 ms one wavefront per page)
 constexpr int kMaxDevices = 64;
 std::mutex g_grid_mutex;
 Grids g_grids[kMaxDevices];
@@ -222,16 +226,26 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     {   // a batch that cannot hold more pages than that needs no more wavefronts (every page is at least 32 KiB of the caller's output
         // region): a single asset launches a handful of workgroups instead of 4 096.  (The kernel itself sends home every wavefront beyond
         // the batch's page count before it touches the page counter -- that is what takes 45 us off a single page; round 4.)
+        // Which kernel: up to kDuoMaxPages pages two wavefronts per page (brotlig_decode_duo_kernel), more than that one wavefront per
+        // one or two pages.  The host knows the output size, not the page count (32 .. 128 KiB each): where the size leaves both
+        // possible (up to 256 MiB of output) both kernels are launched and the one the batch does not belong to leaves at once
+        // (DecodeArgs::duo_limit against the page count the prepare kernel found) -- a few microseconds, and only for such batches.
         const uint64_t bound = max_pages(a.num_streams, a.out_bytes);
         const uint32_t mode = g_debug_mode.load(), forced = g_debug_grid.load();
-        if (mode == 2u || (mode == 0u && forced == 0u && bound <= kDuoMaxPages)) {
-            // few pages: two wavefronts per page, entropy decode and assembly a group apart (brotlig_kernels.h, duo_producer / duo_consumer)
+        DecodeArgs b = a;
+        b.duo_limit = (mode == 1u || forced != 0u) ? 0u : mode == 2u ? 0xFFFFFFFFu : (uint32_t)kDuoMaxPages;
+        if (mode != 2u && a.out_bytes / kMaxPageSize > kDuoMaxPages) b.duo_limit = 0u;     // an output this large is taken for more pages than that
+        const bool duo = b.duo_limit != 0u;
+        const bool classic = !duo || (mode != 2u && bound > kDuoMaxPages);
+        if (duo) {
             const unsigned grid = bound < (uint64_t)g.duo ? (unsigned)(bound ? bound : 1u) : (unsigned)g.duo;
-            hipLaunchKernelGGL(brotlig_decode_duo_kernel, dim3(grid), dim3(128), 0, s, a);
-        } else {
+            hipLaunchKernelGGL(brotlig_decode_duo_kernel, dim3(grid), dim3(128), 0, s, b);
+        }
+        if (classic) {
+            // a batch that cannot hold more pages than that needs no more wavefronts (every page is at least 32 KiB of the caller's output region)
             unsigned grid = bound < (uint64_t)g.decode ? (unsigned)(bound ? bound : 1u) : (unsigned)g.decode;
             if (forced) grid = forced < (unsigned)g.decode ? forced : (unsigned)g.decode;
-            hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, b);
         }
     }
     if (k1) HIP_OK(hipEventRecord(k1, s));

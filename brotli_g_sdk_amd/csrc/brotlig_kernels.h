@@ -78,6 +78,9 @@ struct DecodeArgs {
                             // [8..23] pages per scheduling bucket, [24..39] bucket fill cursors
     uint32_t* order;        // [order_cap] page schedule: global page indices grouped by bucket (null: page order)
     uint32_t  order_cap;
+    uint32_t  duo_limit;    // batches of up to this many pages belong to brotlig_decode_duo_kernel (two wavefronts per page), larger ones to
+                            // brotlig_decode_kernel: the host launches both when it cannot tell (it knows the output size, not the page
+                            // count) and the one the batch does not belong to leaves at once.  0: never the former, ~0: always
     DcTable*  dc;           // [num_streams]
     uint16_t* far_syms;     // [workgroups of the decode grid][2][kFarSymStride] per 32-lane half: the ICP and distance symbols
                             // (canonical-code order) that do not fit the LDS arrays -- ranks kIcpSymCap.. and kDistSymCap..
@@ -969,6 +972,9 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
 // level without long pieces runs one lane per piece; otherwise the ready pieces share the 32 lanes as teams, 8 bytes per
 // lane per step.  Overlapping copies replay their pattern modulo the distance, so a copy never waits for itself.
 // Pieces with `far_direct` went from registers straight to their place and take no part.
+#ifndef BROTLIG_TUNE_MASK_LEVELS
+#define BROTLIG_TUNE_MASK_LEVELS 1
+#endif
 #ifndef BROTLIG_TUNE_PLAIN_LEVELS
 #define BROTLIG_TUNE_PLAIN_LEVELS 1
 #endif
@@ -983,6 +989,28 @@ __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* 
     const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
     const uint8_t* const sp = far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx;
     uint8_t* const dp = win + dst_idx;
+#if BROTLIG_TUNE_MASK_LEVELS
+    // The level loop's questions as wave-wide lane masks in scalar registers (wave::from_mask turns a mask back into a lane predicate
+    // without an instruction): the ballot of a COMPOUND predicate goes through a 0 / 1 register and a second compare.
+    uint64_t todo_w = wave::ballot64(plen != 0u && !far_direct);
+    uint32_t todo = wave::half_of(todo_w);
+    const uint64_t ge8_w = wave::ballot64(plen >= 8u);
+    while (todo_w != 0ull) {
+        clk.count(kPhLevels, 1);
+        clk.halves(kPhLevelHalves, todo != 0u);
+        const uint64_t ready_w = todo_w & wave::ballot64((todo & dep_mask) == 0u);
+        if (wave::from_mask(ready_w & ge8_w)) {
+            const Chunks32 c = load_chunks32(sp, plen, clip8);
+            store_chunks32(dp, c, plen, clip8);
+        }
+        if (wave::from_mask(ready_w & ~ge8_w)) store_bytes(dp, load_u64u(sp), plen);
+        clk.lap(kPhLvShort);
+        todo &= ~wave::half_of(ready_w);
+        todo_w &= ~ready_w;
+        wave::sync();
+    }
+    (void)sl;
+#else
     uint32_t todo = wave::half_ballot(plen != 0u && !far_direct);
     while (wave::any(todo != 0u)) {
         clk.count(kPhLevels, 1);
@@ -1001,6 +1029,7 @@ __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* 
         todo &= ~ready_mask;
         wave::sync();
     }
+#endif
 }
 
 template <class Clock>
@@ -1013,6 +1042,21 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
     // simple piece: pattern in one place (window or staging area) and no chunk of a 32-byte batch reads
     // what an earlier chunk of the batch wrote
     const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
+#if BROTLIG_TUNE_MASK_LEVELS
+    // (the questions of the level loop as wave-wide lane masks in scalar registers, see copy_levels_plain)
+    uint64_t todo_w = wave::ballot64(plen != 0u && !far_direct && !(kAblate & kAblLevels));
+    uint32_t todo = wave::half_of(todo_w);
+    const uint64_t simple_w = wave::ballot64(simple);
+    const uint64_t long_w = wave::ballot64(plen > (simple ? kOwnCopy : kShortCopy));
+    const uint64_t ge8_w = wave::ballot64(plen >= 8u), gt32_w = wave::ballot64(plen > 32u);
+    while (todo_w != 0ull) {
+        clk.count(kPhLevels, 1);
+        clk.halves(kPhLevelHalves, todo != 0u);
+        const uint64_t ready_w = todo_w & wave::ballot64((todo & dep_mask) == 0u);
+        const bool ready = wave::from_mask(ready_w);
+        const uint32_t ready_mask = wave::half_of(ready_w);
+        if ((kAblate & kAblTeams) || (ready_w & long_w) == 0ull) {
+#else
     uint32_t todo = wave::half_ballot(plen != 0u && !far_direct && !(kAblate & kAblLevels));
     while (wave::any(todo != 0u)) {
         clk.count(kPhLevels, 1);
@@ -1020,6 +1064,7 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
         const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
         const uint32_t ready_mask = wave::half_ballot(ready);
         if ((kAblate & kAblTeams) || !wave::any(ready && (plen > (simple ? kOwnCopy : kShortCopy)))) {
+#endif
             // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
             // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
             // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
@@ -1028,6 +1073,18 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx;
             uint8_t* dp = win + dst_idx;
             const bool whole = far_len == 0u || far_len == pattern;
+#if BROTLIG_TUNE_MASK_LEVELS
+            const uint64_t a_w = (kAblate & kAblOwnLane) ? 0ull : ready_w & simple_w, b_w = (kAblate & kAblOverlap) ? 0ull : ready_w & ~simple_w;
+            const bool lane_b = wave::from_mask(b_w);
+            if (wave::from_mask(a_w & ge8_w)) {
+                const Chunks32 c = load_chunks32(sp, plen, clip8);
+                store_chunks32(dp, c, plen, clip8);
+            }
+            if (wave::from_mask(a_w & ~ge8_w)) store_bytes(dp, load_u64u(sp), plen);
+            uint64_t more_w = a_w & gt32_w;
+            for (uint32_t o = 32u; more_w != 0ull; o += 32u, more_w &= wave::ballot64(plen > o)) {      // further batches: bytes o .. min(o + 32, plen) - 1
+                if (wave::from_mask(more_w)) {
+#else
             const bool lane_a = ready && simple && !(kAblate & kAblOwnLane);
             const bool lane_b = ready && !simple && !(kAblate & kAblOverlap);
             if (lane_a) {
@@ -1040,6 +1097,7 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             }
             for (uint32_t o = 32u; wave::any(lane_a && plen > o); o += 32u) {      // further batches: bytes o .. min(o + 32, plen) - 1
                 if (lane_a && plen > o) {
+#endif
                     const uint32_t c0 = min_u32(o, clip8), c1 = min_u32(o + 8u, clip8), c2 = min_u32(o + 16u, clip8), c3 = min_u32(o + 24u, clip8);
                     uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
                     v0 = load_u64u(sp + c0);
@@ -1053,7 +1111,11 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
                 }
             }
             clk.lap(kPhLvShort);
+#if BROTLIG_TUNE_MASK_LEVELS
+            if (b_w != 0ull) {
+#else
             if (wave::any(lane_b)) {
+#endif
                 // The rest.  Self-overlapping pieces with a distance below 32 are copied forward in
                 // 8-byte chunks from `dd` bytes back, each chunk reading what its predecessors wrote
                 // (LDS accesses of a wave execute in order); a distance below 8 first lays down eight
@@ -1140,6 +1202,9 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
         clk.lap(kPhLvBytes);
         }
         todo &= ~ready_mask;
+#if BROTLIG_TUNE_MASK_LEVELS
+        todo_w &= ~ready_w;
+#endif
         wave::sync();
     }
 }
@@ -2156,7 +2221,8 @@ __global__ void __launch_bounds__(128) brotlig_decode_duo_kernel(DecodeArgs a)
     if (t < 48u) D.len_code_tab[t] = kLenCodeTab[t];
     if (t == 0u) { D.produced = 0u; D.consumed = 0u; }
     __syncthreads();
-    if (blockIdx.x >= a.page_base[a.num_streams]) return;               // more workgroups than pages
+    const uint32_t total = a.page_base[a.num_streams];
+    if (blockIdx.x >= total || total > a.duo_limit) return;             // more workgroups than pages, or a batch for brotlig_decode_kernel
     if (t < 64u) duo_producer(D, a); else duo_consumer(D, a);
 }
 
@@ -2498,7 +2564,8 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
     // neighbour: every phase of a round costs the maximum over the two halves).  So the upper halves only take part in as many
     // wavefronts as there are pages beyond one per wavefront; from two pages per wavefront on, every half works.
     const uint32_t total0 = a.page_base[a.num_streams];
-    if (blockIdx.x >= total0) return;       // more wavefronts than pages: the surplus leaves before it takes a turn at the page counter
+    if (blockIdx.x >= total0 || total0 <= a.duo_limit) return;     // more wavefronts than pages: the surplus leaves before it takes a turn at the
+                                                                    // page counter; all of them when the batch is the two-wavefront kernel's
     const uint32_t doubles = total0 > gridDim.x ? total0 - gridDim.x : 0u;     // wavefronts that need both halves
     if (blockIdx.x >= doubles) decode_pages<kProf, true>(W, a, prof_lds);
     else decode_pages<kProf, false>(W, a, prof_lds);

@@ -26,6 +26,9 @@ __device__ __forceinline__ uint32_t lane_id_fresh()
 // v_cmp per call on top of the compare that produced the predicate; round 4, ~40 ballots per round)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// A lane mask (the same in every lane: a ballot, or scalar arithmetic on ballots) as a lane predicate: no instruction, the mask IS the
+// condition register.  Lets the compound questions of a loop be asked as s_and / s_andn2 on masks instead of per-lane logic.
+__device__ __forceinline__ bool from_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // Value of `v` in lane `src` (0..63) of the wave.
 __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src)
 {
@@ -42,6 +45,9 @@ __device__ __forceinline__ uint32_t half_ballot(bool p)
     const uint64_t m = __builtin_amdgcn_ballot_w64(p);
     return (uint32_t)(m >> (lane_id() & 32u));
 }
+
+// The caller's half of a wave-wide mask.
+__device__ __forceinline__ uint32_t half_of(uint64_t m) { return (uint32_t)(m >> (lane_id() & 32u)); }
 
 // Value of `v` in lane `src` (0..31) of the caller's half.
 __device__ __forceinline__ uint32_t half_shfl(uint32_t v, uint32_t src)

@@ -233,7 +233,7 @@ const uint8_t* BrotligStreamerOutput(BrotligStreamer* streamer, uint64_t ticket,
  * path as well as the one-page path it gets by default.  Process-wide. */
 void BrotligDebugSetDecodeGrid(uint32_t workgroups);
 /* Diagnostics, for tests and the latency report: which decode kernel a launch uses -- 0 = the normal rule (two wavefronts per page
- * for batches that cannot hold more than 1 024 pages, one wavefront per one or two pages otherwise), 1 = never the two-wavefront
+ * for batches of up to 2 048 pages, one wavefront per one or two pages otherwise), 1 = never the two-wavefront
  * kernel, 2 = always.  Process-wide. */
 void BrotligDebugSetDecodeMode(uint32_t mode);
 

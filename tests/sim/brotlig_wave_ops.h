@@ -20,6 +20,8 @@ inline uint64_t ballot64(bool p, SIM_SITE)
     return m;
 }
 inline bool any(bool p, SIM_SITE) { return ballot64(p, site) != 0; }
+inline bool from_mask(uint64_t m) { return ((m >> lane_id()) & 1u) != 0u; }
+inline uint32_t half_of(uint64_t m) { return (uint32_t)(m >> (lane_id() & 32u)); }
 inline uint32_t bcast(uint32_t v, uint32_t src, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);

@@ -51,7 +51,7 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     sim::run_grid(1, prepare_body, &a);
     if (a.order) { sim::run_grid(3, order_count_body, &a); sim::run_grid(3, order_scatter_body, &a); }
     sim::run_grid(1, policy_body, &a);
-    if (g_duo) { ++g_duo_launches; sim::run_grid(decode_grid, duo_body, &a, 2); }
+    if (g_duo) { ++g_duo_launches; a.duo_limit = 0xFFFFFFFFu; sim::run_grid(decode_grid, duo_body, &a, 2); a.duo_limit = 0u; }
     else sim::run_grid(decode_grid, decode_body, &a);
     sim::run_grid(3, decond_body, &a);
     *status_out = status_words[0];

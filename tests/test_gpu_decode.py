@@ -143,6 +143,29 @@ def test_batch_mixed_plain_and_preconditioned(api):
         assert rc == 0 and np.array_equal(dec.output(i), ref), i
 
 
+def test_kernel_choice_follows_the_page_count(api):
+    """Up to 2 048 pages a batch is decoded two wavefronts per page (brotlig_decode_duo_kernel), beyond that one wavefront per one or
+    two pages (brotlig_decode_kernel).  The host only knows the output size: for 64 .. 256 MiB both kernels are launched and each
+    reads the page count the prepare kernel found (DecodeArgs::duo_limit) -- exactly one of them decodes.  Page counts on both sides
+    of the limit and of the sizes at which the host stops launching one of the two; every tiled repeat against the source bytes,
+    under the size rule and with either kernel pinned."""
+    base = D.mixed(32 * 65536, 21)
+    small = E.encode(base)
+    for reps in (1, 9, 33, 63, 64, 65, 100, 129):        # 32 .. 4 128 pages, 2 .. 258 MiB
+        stream = D.tile_stream(small, reps)
+        dec = api.BatchDecoder([stream])
+        for mode in (0, 1, 2) if reps in (1, 65) else (0,):
+            api.DebugSetDecodeMode(mode)
+            try:
+                dec.poison_output()
+                dec.decode()
+                out = dec.output(0)
+                assert np.array_equal(out.reshape(reps, -1), np.broadcast_to(base, (reps, len(base)))), (reps, mode)
+            finally:
+                api.DebugSetDecodeMode(0)
+        del dec
+
+
 def test_repeated_decode_is_idempotent(api):
     d = D.mixed(8 * 65536, 3)
     dec = api.BatchDecoder([E.encode(d)])
