@@ -161,7 +161,7 @@ constexpr uint32_t kAblate = BROTLIG_ABLATE;
 #endif
 #ifndef BROTLIG_TUNE_ROUND_MAX
 #define BROTLIG_TUNE_ROUND_MAX 640      // round 4: groups of 640 bytes (history 656, window 1344): mixed +1.7 %, records +6.6 %, text -0.6 %, samples16 +0.2 %
-#define BROTLIG_TUNE_WIN 1328      // (1 344 until the ring moved to LDS: 16 bytes per page)
+#define BROTLIG_TUNE_WIN 1344
 #define BROTLIG_TUNE_DIST_LUT_BITS 8
 #endif
 #ifndef BROTLIG_TUNE_EARLY_NEAR
@@ -257,8 +257,7 @@ struct __attribute__((aligned(16))) PageLdsT {
     uint8_t  start_cum[G::kRoundMax / 32];  // per group: piece starts in earlier words of start_bits
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
     uint32_t page_params;           // NPOSTFIX | (NDIRECT << NPOSTFIX) << 8 | delta-coded flag << 16 of the page being decoded
-    uint32_t ring_push[2][4] __attribute__((aligned(16)));  // the last four distances pushed in a round, most recent first (two rounds alternate)
-    uint32_t ring_state[4] __attribute__((aligned(16)));    // the distance ring as of the start of the previous round's pushes (resolve_distance_ring)
+    uint32_t ring[8] __attribute__((aligned(16)));  // the distance ring, circular: the t-th distance pushed in the page lives in word t & 7 (DistanceRing)
     uint8_t  win[G::kWin + 16] __attribute__((aligned(16)));    // output window; doubles as the code-length
                                                                  // scratch (728 B) while tables are built
 };
@@ -1538,50 +1537,32 @@ __device__ __forceinline__ RoundCommands decode_round_commands(const Lds& L, con
     return c;
 }
 
-// ---- stage: the distance ring (PageDecoder.cpp:345-364, :396-403).  The ring proper lives in registers; the last four
-// distances pushed in a round travel to the next round through LDS (ring_push, two rounds alternate).
-// Round 4: the ring itself lives in LDS between rounds (Lds::ring_state, four words), not in registers: its four values are only
-// needed inside resolve_distance_ring, and four registers live across a whole round were what the register allocator paid for
-// with a scratch store and reload per round whenever the rest of the kernel changed a little (-4.7 % when it happened).
+// ---- stage: the distance ring (PageDecoder.cpp:345-364, :396-403): the last four distances pushed, most recent first.
+// It lives in LDS as a circular buffer of eight words: the t-th distance pushed in the page (t counts from 4: the four initial
+// entries 16, 15, 11, 4 are pushes 0..3) sits in word t & 7, and all a lane keeps is the page's push count so far.  The q-th most
+// recent push before a round is word (T - 1 - q) & 7 -- ONE LDS read per lane, for the lanes that need a carried entry at all --
+// and a round stores its last four pushes in words T .. T + cnt - 1 (& 7): they cannot meet the four words below T that the same
+// round still reads (eight consecutive push numbers at most).  Rounds 1-3 kept the four entries in registers and folded the previous
+// round's pushes in with a chain of selects on the push count (sixteen v_cndmask a round, on a kernel bound by the vector ALU).
 struct DistanceRing {
-    uint32_t cnt = 0, par = 0;                      // pushes of the previous round still to be folded in, and where they are
+    uint32_t total = 4;                             // pushes of the page so far, the four initial entries included
     template <class Lds> __device__ __forceinline__ void reset(Lds& L, bool starting, uint32_t sl)
     {
-        // 4, 11, 15, 16 (PageDecoder.cpp:150-153), one word per lane out of a packed constant: written as four constants the compiler
-        // builds a constant vector, keeps it in four registers for the whole kernel, spills it and reloads it in every round
-        if (starting && sl < 4u) L.ring_state[sl] = (0x100F0B04u >> (8u * sl)) & 0xFFu;
-        if (starting) cnt = 0;
+        // 4, 11, 15, 16 most recent first (PageDecoder.cpp:150-153) = pushes 3, 2, 1, 0; one word per lane out of a packed constant
+        // (four constants become a constant vector that is kept in registers for the whole kernel, spilled, and reloaded every round)
+        if (starting && sl < 4u) L.ring[sl] = (0x040B0F10u >> (8u * sl)) & 0xFFu;
+        if (starting) total = 4u;
     }
 };
-struct RingWords { Bytes16 pushed, state; };
-// the ring and the previous round's pushes: read at the top of a round, folded together by resolve_distance_ring
+struct RingWords {};                                // (rounds 1-3: the ring words, loaded at the top of a round)
 template <class Lds>
-__device__ __forceinline__ RingWords load_ring_pushes(const Lds& L, const DistanceRing& ring)
-{
-    RingWords w;
-    w.pushed = Bytes16{0u, 0u, 0u, 0u};
-    w.state = *reinterpret_cast<const Bytes16*>(L.ring_state);
-    if (ring.cnt) w.pushed = *reinterpret_cast<const Bytes16*>(L.ring_push[ring.par ^ 1u]);
-    return w;
-}
+__device__ __forceinline__ RingWords load_ring_pushes(const Lds&, const DistanceRing&) { return RingWords{}; }
 // Codes 1..15 are resolved in command order; explicit distances and code 0 need no serial step.  On return c.dist
 // is final for every copy command of the round.
 template <class Lds>
-__device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring, const RingWords& w, RoundCommands& c, uint32_t sl)
+__device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring, const RingWords&, RoundCommands& c, uint32_t sl)
 {
-    uint32_t r0 = w.state[0], r1 = w.state[1], r2 = w.state[2], r3 = w.state[3];
-    {   // new ring = the last four pushed distances (PageDecoder.cpp:396-403)
-        const Bytes16& pushed = w.pushed;
-        const uint32_t o0 = r0, o1 = r1, o2 = r2;
-        if (ring.cnt >= 4u) { r0 = pushed[0]; r1 = pushed[1]; r2 = pushed[2]; r3 = pushed[3]; }
-        else if (ring.cnt == 3u) { r0 = pushed[0]; r1 = pushed[1]; r2 = pushed[2]; r3 = o0; }
-        else if (ring.cnt == 2u) { r0 = pushed[0]; r1 = pushed[1]; r2 = o0; r3 = o1; }
-        else if (ring.cnt == 1u) { r0 = pushed[0]; r1 = o0; r2 = o1; r3 = o2; }
-        if (ring.cnt != 0u && sl == 0u) {                           // (every lane of the half has read the old words: LDS accesses execute in order)
-            const Bytes16 next = {r0, r1, r2, r3};
-            *reinterpret_cast<Bytes16*>(L.ring_state) = next;
-        }
-    }
+    const uint32_t T = ring.total;
     const uint32_t dcode = c.dcode;
     uint32_t dist = c.dist;
     const bool is_copy = c.is_cmd && c.copy > 0u;
@@ -1589,19 +1570,21 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
     // A code 1..15 refers to the r-th most recent push before the command (r from the code): either
     // a command of this round (lane `src`) or the ring carried in from earlier rounds.  All lanes
     // whose source is already known resolve together; a chain of ring codes takes one pass per link
-    // (the lowest unresolved lane is always resolvable).
+    // (the lowest unresolved lane is always resolvable).  Code 0 ("the last distance") is r = 0 without a push: it waits
+    // until the chains are done.
     uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
+    const uint32_t r = dcode < 4u ? dcode : (dcode < 10u ? 0u : 1u);
+    const uint32_t below0 = push_mask & ((1u << sl) - 1u);
+    uint32_t below = below0;
+    const uint32_t cnt = (uint32_t)__popc(below);
+    // the carried entry r - cnt (when the round has fewer than r + 1 pushes before me): requested now, used in the loop
+    const uint32_t carried = L.ring[(T - 1u - (r - cnt)) & 7u];
     {
-        const uint32_t r = dcode < 4u ? dcode : (dcode < 10u ? 0u : 1u);
-        uint32_t below = push_mask & ((1u << sl) - 1u);
-        const uint32_t cnt = (uint32_t)__popc(below);
         if (r >= 1u && below) below &= ~(1u << msb_u32(below));
         if (r >= 2u && below) below &= ~(1u << msb_u32(below));
         if (r >= 3u && below) below &= ~(1u << msb_u32(below));
-        const bool from_round = r < cnt;                            // else: carried ring entry r - cnt
+        const bool from_round = r < cnt;
         const uint32_t src = from_round ? msb_u32(below) : 0u;
-        const uint32_t q = r - cnt;
-        const uint32_t carried = q == 0u ? r0 : q == 1u ? r1 : q == 2u ? r2 : r3;
         const uint32_t j = dcode >= 4u ? (dcode - 4u) % 6u : 0u, mag = dcode >= 4u ? (j >> 1) + 1u : 0u;
         while (wave::any(pend != 0u)) {
             const bool mine = ((pend >> sl) & 1u) != 0u;
@@ -1615,15 +1598,14 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
         }
     }
     {
-        const uint32_t below = push_mask & ((1u << sl) - 1u);
-        const uint32_t from = wave::half_shfl(dist, below ? msb_u32(below) : 0u);
-        if (is_copy && dcode == 0u) dist = below ? from : r0;
-        // the round's last four pushes go to LDS, most recent first; the next round folds them into the ring
+        const uint32_t from = wave::half_shfl(dist, below0 ? msb_u32(below0) : 0u);
+        if (is_copy && dcode == 0u) dist = below0 ? from : carried;     // (r = 0, cnt = 0: `carried` is the most recent push of earlier rounds)
+        // the round's last four pushes go to the ring
         const bool pusher = is_copy && dcode != 0u;
         const uint32_t above = (uint32_t)__popc((push_mask >> sl) >> 1);    // pushes after mine
-        if (pusher && above < 4u) L.ring_push[ring.par][above] = dist;
-        ring.cnt = (uint32_t)__popc(push_mask);
-        ring.par ^= 1u;
+        const uint32_t pushes = (uint32_t)__popc(push_mask);
+        if (pusher && above < 4u) L.ring[(T + pushes - 1u - above) & 7u] = dist;
+        ring.total = T + pushes;
     }
     c.dist = dist;
 }

@@ -58,8 +58,7 @@ struct __attribute__((aligned(16))) EntropyLds {       // one per 32-lane half
     uint16_t limit[3][16] __attribute__((aligned(16)));
     uint32_t first_offs[3][16];
     uint32_t page_params;
-    uint32_t ring_push[2][4] __attribute__((aligned(16)));
-    uint32_t ring_state[4] __attribute__((aligned(16)));
+    uint32_t ring[8] __attribute__((aligned(16)));
 };
 static_assert(kLutBitsIcp == 8 && kLutBitsDist == 8 && kLutBitsLit == 8, "build areas are laid out for three 512-byte LUTs");
 static_assert(__builtin_offsetof(EntropyLds, build_tail) == 1536 && __builtin_offsetof(EntropyLds, lit_lens) == 1536 + 544, "build areas must follow the LUTs");
