@@ -459,19 +459,18 @@ __device__ __forceinline__ void store_chunks32(uint8_t* dp, const Chunks32& c, u
 // Copy of `len` bytes by the lane itself when no chunk of a 32-byte batch reads what an earlier chunk of the batch
 // wrote (no overlap, or distance >= 32): 8-byte chunks at offsets clipped to len - 8 (the last chunk ends at the
 // piece's end and overlaps its predecessor), the loads of a batch before its stores.
-__device__ __forceinline__ void own_copy_simple(const uint8_t* sp, uint8_t* dp, uint32_t len, bool on)
+__device__ __forceinline__ void own_copy_simple(const uint8_t* sp, uint8_t* dp, uint32_t len, uint64_t on_w)
 {
     const uint32_t clip8 = len >= 8u ? len - 8u : 0u;
-    if (on) {
-        if (len >= 8u) {
-            const Chunks32 c = load_chunks32<BROTLIG_TUNE_LIT_CHUNKS>(sp, len, clip8);
-            store_chunks32<BROTLIG_TUNE_LIT_CHUNKS>(dp, c, len, clip8);
-        } else {
-            store_bytes(dp, load_u64u(sp), len);
-        }
+    const uint64_t ge8_w = wave::ballot_gt_k<7u>(len);
+    if (wave::from_mask(on_w & ge8_w)) {
+        const Chunks32 c = load_chunks32<BROTLIG_TUNE_LIT_CHUNKS>(sp, len, clip8);
+        store_chunks32<BROTLIG_TUNE_LIT_CHUNKS>(dp, c, len, clip8);
     }
-    for (uint32_t o = 32u; wave::any(on && len > o); o += 32u) {
-        if (on && len > o) {
+    if (wave::from_mask(on_w & ~ge8_w)) store_bytes(dp, load_u64u(sp), len);
+    uint64_t more_w = on_w & wave::ballot_gt_k<32u>(len);
+    for (uint32_t o = 32u; more_w != 0ull; o += 32u, more_w &= wave::ballot_gt(len, o)) {
+        if (wave::from_mask(more_w)) {
             const uint32_t c0 = min_u32(o, clip8), c1 = min_u32(o + 8u, clip8), c2 = min_u32(o + 16u, clip8), c3 = min_u32(o + 24u, clip8);
             uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
             v0 = load_u64u(sp + c0);
@@ -909,7 +908,8 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
 template <class G = GeoPair>
 __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed, uint8_t* out, bool on, uint32_t gpos, uint32_t gend, uint32_t sl)
 {
-    const bool slide = on && gend > view.win_base + G::kWin && !(kAblate & kAblSlide);
+    const uint64_t slide_w = (kAblate & kAblSlide) ? 0ull : wave::ballot64(on) & wave::ballot_gt(gend, view.win_base + G::kWin);
+    const bool slide = wave::from_mask(slide_w);
     wave::sync();
     // (the two-piece and the three-piece forms are written out separately: with the third piece as a folded-away branch inside
     // the two-piece code the compiler dropped the skip branches around the second store and issued it with an empty mask --
@@ -937,7 +937,7 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
         if (f2) store16(out + p2, a2);
         if (on && e16 > flushed) flushed = e16;
     }
-    if (wave::any(slide)) {
+    if (slide_w != 0ull) {
         const uint32_t nb = slide ? (gpos - G::kHist) & ~15u : view.win_base;
         const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
         if constexpr (G::kSlidePieces <= 2u) {
@@ -983,7 +983,7 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
 // instructions, 3.7 levels a round; text pages take this path in nearly every group.)
 template <class Clock>
 __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* stage, uint32_t plen, uint32_t far_len, uint32_t stage_off,
-                                                  uint32_t src_idx, uint32_t dst_idx, bool far_direct, uint32_t dep_mask, uint32_t sl, Clock& clk)
+                                                  uint32_t src_idx, uint32_t dst_idx, uint64_t direct_w, uint32_t dep_mask, uint32_t sl, Clock& clk)
 {
     const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
     const uint8_t* const sp = far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx;
@@ -991,13 +991,13 @@ __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* 
 #if BROTLIG_TUNE_MASK_LEVELS
     // The level loop's questions as wave-wide lane masks in scalar registers (wave::from_mask turns a mask back into a lane predicate
     // without an instruction): the ballot of a COMPOUND predicate goes through a 0 / 1 register and a second compare.
-    uint64_t todo_w = wave::ballot64(plen != 0u && !far_direct);
+    uint64_t todo_w = wave::ballot_ne0(plen) & ~direct_w;
     uint32_t todo = wave::half_of(todo_w);
-    const uint64_t ge8_w = wave::ballot64(plen >= 8u);
+    const uint64_t ge8_w = wave::ballot_gt_k<7u>(plen);
     while (todo_w != 0ull) {
         clk.count(kPhLevels, 1);
         clk.halves(kPhLevelHalves, todo != 0u);
-        const uint64_t ready_w = todo_w & wave::ballot64((todo & dep_mask) == 0u);
+        const uint64_t ready_w = todo_w & wave::ballot_eq0(todo & dep_mask);
         if (wave::from_mask(ready_w & ge8_w)) {
             const Chunks32 c = load_chunks32(sp, plen, clip8);
             store_chunks32(dp, c, plen, clip8);
@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* 
     }
     (void)sl;
 #else
-    uint32_t todo = wave::half_ballot(plen != 0u && !far_direct);
+    uint32_t todo = wave::half_of(wave::ballot_ne0(plen) & ~direct_w);
     while (wave::any(todo != 0u)) {
         clk.count(kPhLevels, 1);
         clk.halves(kPhLevelHalves, todo != 0u);
@@ -1033,30 +1033,32 @@ __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* 
 
 template <class Clock>
 __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage, uint32_t plen, uint32_t dist, uint32_t far_len, uint32_t stage_off,
-                                            uint32_t src_idx, uint32_t dst_idx, bool far_direct, uint32_t dep_mask, uint32_t sl, bool solo, Clock& clk)
+                                            uint32_t src_idx, uint32_t dst_idx, uint64_t direct_w, uint32_t dep_mask, uint32_t sl, bool solo, Clock& clk)
 {
     const uint32_t pattern = min_u32(plen, dist);
     const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
     const uint32_t packed = plen | (far_len << 11) | ((stage_off >> 3) << 22);
     // simple piece: pattern in one place (window or staging area) and no chunk of a 32-byte batch reads
     // what an earlier chunk of the batch wrote
-    const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
 #if BROTLIG_TUNE_MASK_LEVELS
     // (the questions of the level loop as wave-wide lane masks in scalar registers, see copy_levels_plain)
-    uint64_t todo_w = wave::ballot64(plen != 0u && !far_direct && !(kAblate & kAblLevels));
+    uint64_t todo_w = (kAblate & kAblLevels) ? 0ull : wave::ballot_ne0(plen) & ~direct_w;
     uint32_t todo = wave::half_of(todo_w);
-    const uint64_t simple_w = wave::ballot64(simple);
-    const uint64_t long_w = wave::ballot64(plen > (simple ? kOwnCopy : kShortCopy));
-    const uint64_t ge8_w = wave::ballot64(plen >= 8u), gt32_w = wave::ballot64(plen > 32u);
+    const uint64_t whole_w = wave::ballot_eq0(far_len) | wave::ballot_eq(far_len, pattern);         // pattern in one place
+    const uint64_t simple_w = whole_w & (wave::ballot_gt_k<31u>(dist) | ~wave::ballot_lt(dist, plen));
+    const bool simple = wave::from_mask(simple_w);
+    const uint64_t long_w = (simple_w & wave::ballot_gt_k<kOwnCopy>(plen)) | (~simple_w & wave::ballot_gt_k<kShortCopy>(plen));
+    const uint64_t ge8_w = wave::ballot_gt_k<7u>(plen), gt32_w = wave::ballot_gt_k<32u>(plen);
     while (todo_w != 0ull) {
         clk.count(kPhLevels, 1);
         clk.halves(kPhLevelHalves, todo != 0u);
-        const uint64_t ready_w = todo_w & wave::ballot64((todo & dep_mask) == 0u);
+        const uint64_t ready_w = todo_w & wave::ballot_eq0(todo & dep_mask);
         const bool ready = wave::from_mask(ready_w);
         const uint32_t ready_mask = wave::half_of(ready_w);
         if ((kAblate & kAblTeams) || (ready_w & long_w) == 0ull) {
 #else
-    uint32_t todo = wave::half_ballot(plen != 0u && !far_direct && !(kAblate & kAblLevels));
+    const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
+    uint32_t todo = (kAblate & kAblLevels) ? 0u : wave::half_of(wave::ballot_ne0(plen) & ~direct_w);
     while (wave::any(todo != 0u)) {
         clk.count(kPhLevels, 1);
         clk.halves(kPhLevelHalves, todo != 0u);
@@ -1071,7 +1073,11 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             // has another ready piece inside its source).
             const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx;
             uint8_t* dp = win + dst_idx;
+#if BROTLIG_TUNE_MASK_LEVELS
+            const bool whole = wave::from_mask(whole_w);
+#else
             const bool whole = far_len == 0u || far_len == pattern;
+#endif
 #if BROTLIG_TUNE_MASK_LEVELS
             const uint64_t a_w = (kAblate & kAblOwnLane) ? 0ull : ready_w & simple_w, b_w = (kAblate & kAblOverlap) ? 0ull : ready_w & ~simple_w;
             const bool lane_b = wave::from_mask(b_w);
@@ -1081,7 +1087,7 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             }
             if (wave::from_mask(a_w & ~ge8_w)) store_bytes(dp, load_u64u(sp), plen);
             uint64_t more_w = a_w & gt32_w;
-            for (uint32_t o = 32u; more_w != 0ull; o += 32u, more_w &= wave::ballot64(plen > o)) {      // further batches: bytes o .. min(o + 32, plen) - 1
+            for (uint32_t o = 32u; more_w != 0ull; o += 32u, more_w &= wave::ballot_gt(plen, o)) {      // further batches: bytes o .. min(o + 32, plen) - 1
                 if (wave::from_mask(more_w)) {
 #else
             const bool lane_a = ready && simple && !(kAblate & kAblOwnLane);
@@ -1270,18 +1276,24 @@ struct FarSources {
     uint32_t t_src, t_len, t_stage; // the team's piece: page position of its source, far bytes, staging offset
     uint32_t stage_off;             // this lane's piece: 8-byte aligned offset into the staging area
     bool     direct, staged, any_staged, teams;
+    uint64_t direct_w;              // `direct` of every lane (wave-wide mask)
 };
 __device__ __forceinline__ FarSources fetch_far_sources(const uint8_t* out, const uint8_t* win, uint32_t src_idx, bool near_direct,
                                                         uint32_t plen, uint32_t psrc, uint32_t far_len, uint32_t sl)
 {
     FarSources f;
-    f.direct = (far_len != 0u && far_len == plen && plen <= kShortCopy) || near_direct;
-    f.staged = far_len != 0u && !f.direct;
+    // (the questions as lane masks: see wave::ballot_gt)
+    const uint64_t far_w = wave::ballot_ne0(far_len);
+    f.direct_w = far_w & wave::ballot_eq(far_len, plen) & wave::ballot_lt_k<kShortCopy + 1u>(plen);
+    if (BROTLIG_TUNE_EARLY_NEAR) f.direct_w |= wave::ballot64(near_direct);
+    const uint64_t staged_w = far_w & ~f.direct_w;
+    f.direct = wave::from_mask(f.direct_w);
+    f.staged = wave::from_mask(staged_w);
     const uint32_t stage_len = f.staged ? (far_len + 7u) & ~7u : 0u;
-    f.any_staged = wave::any(f.staged);
+    f.any_staged = staged_w != 0ull;
     f.stage_off = 0;
     if (f.any_staged) f.stage_off = wave::half_scan_incl(stage_len) - stage_len;
-    f.teams = f.any_staged && wave::any(f.staged && far_len > kShortCopy);
+    f.teams = f.any_staged && (staged_w & wave::ballot_gt_k<kShortCopy>(far_len)) != 0ull;
     f.fe0 = f.fe1 = f.fe2 = f.fe3 = f.te0 = f.te1 = 0;
     f.team = Team{5u, 0u, 0u, false};
     f.t_src = f.t_len = f.t_stage = 0;
@@ -1301,7 +1313,7 @@ __device__ __forceinline__ FarSources fetch_far_sources(const uint8_t* out, cons
         if (plen > 16u) { f.fe2 = load_u64u(s8 + min_u32(16u, clip8)); f.fe3 = load_u64u(s8 + clip8); }
     }
     if (f.teams) {
-        const uint32_t staged_mask = wave::half_ballot(f.staged);
+        const uint32_t staged_mask = wave::half_of(staged_w);
         f.team = make_team(staged_mask, sl);
         f.t_src = wave::half_shfl(psrc, f.team.job); f.t_len = wave::half_shfl(far_len, f.team.job);
         f.t_stage = wave::half_shfl(f.stage_off, f.team.job);
@@ -1492,7 +1504,7 @@ __device__ __forceinline__ RoundCommands decode_round_commands(const Lds& L, con
     uint32_t sym = 0, len = 0;
     if (live) { br.ensure(32); sym = decode_symbol<kLutBitsIcp>(t_icp, br, len); }
     clk.lap(kPhCmdSym);
-    c.sent_mask = wave::half_ballot(live && sym == kSentinel);
+    c.sent_mask = wave::half_of(wave::ballot_eq_k<kSentinel>(sym));          // (sym stays 0 in a half without a page)
     c.n = c.sent_mask ? ctz_u32(c.sent_mask) : 32u;
     c.is_cmd = live && sl < c.n;
     if (live && sl <= c.n) br.consume(len);                           // the sentinel's own bits are consumed too
@@ -1566,13 +1578,13 @@ __device__ __forceinline__ void resolve_distance_ring(Lds& L, DistanceRing& ring
     const uint32_t dcode = c.dcode;
     uint32_t dist = c.dist;
     const bool is_copy = c.is_cmd && c.copy > 0u;
-    const uint32_t push_mask = wave::half_ballot(is_copy && dcode != 0u);
+    const uint32_t push_mask = wave::half_of(wave::ballot_ne0(dcode));        // (a distance code is only decoded for a command with a copy)
     // A code 1..15 refers to the r-th most recent push before the command (r from the code): either
     // a command of this round (lane `src`) or the ring carried in from earlier rounds.  All lanes
     // whose source is already known resolve together; a chain of ring codes takes one pass per link
     // (the lowest unresolved lane is always resolvable).  Code 0 ("the last distance") is r = 0 without a push: it waits
     // until the chains are done.
-    uint32_t pend = wave::half_ballot(is_copy && dcode >= 1u && dcode < 16u);
+    uint32_t pend = wave::half_of(wave::ballot_lt_k<15u>(dcode - 1u));        // codes 1 .. 15
     const uint32_t r = dcode < 4u ? dcode : (dcode < 10u ? 0u : 1u);
     const uint32_t below0 = push_mask & ((1u << sl) - 1u);
     uint32_t below = below0;
@@ -1841,9 +1853,10 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             // -- 4b. literal runs: from the queue to their place in the window (own lane; long inserts in teams)
             if (!(kAblate & kAblLitStore)) {
                 const uint32_t q_idx = lit_f - F0, w_idx = span0 - g0 + la;
-                own_copy_simple(lits + q_idx, L.win + w_idx, nlit, nlit != 0u && nlit <= kOwnCopy);
-                if (wave::any(nlit > kOwnCopy)) {
-                    const uint32_t lmask = wave::half_ballot(nlit > kOwnCopy);
+                own_copy_simple(lits + q_idx, L.win + w_idx, nlit, wave::ballot_lt_k<kOwnCopy>(nlit - 1u));      // 1 <= nlit <= kOwnCopy
+                const uint64_t long_w = wave::ballot_gt_k<kOwnCopy>(nlit);
+                if (long_w != 0ull) {
+                    const uint32_t lmask = wave::half_of(long_w);
                     const Team tl = make_team(lmask, sl);
                     const uint32_t l_src = wave::half_shfl(q_idx, tl.job), l_dst = wave::half_shfl(w_idx, tl.job);
                     const uint32_t l_len = wave::half_shfl(nlit, tl.job);
@@ -1872,15 +1885,14 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             wave::set_priority(1);
 #if BROTLIG_TUNE_PLAIN_LEVELS
             {   // one question per group instead of three per level: does any piece need more than the plain own-lane batch?
-                const uint32_t pat = min_u32(plen, dist);
-                const bool plain_piece = (far_len == 0u || far_len == pat) && dist >= plen && plen <= 32u;      // simple, and one batch
-                if (!kAblate && !wave::any(plen != 0u && !far_direct && !plain_piece))
-                    copy_levels_plain(L.win, L.stage, plen, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
+                const uint64_t plain_w = (wave::ballot_eq0(far_len) | wave::ballot_eq(far_len, pattern)) & ~wave::ballot_lt(dist, plen) & wave::ballot_lt_k<33u>(plen);      // simple, and one batch
+                if (!kAblate && (wave::ballot_ne0(plen) & ~far.direct_w & ~plain_w) == 0ull)
+                    copy_levels_plain(L.win, L.stage, plen, far_len, stage_off, src_idx, dst_idx, far.direct_w, dep_mask, sl, clk);
                 else
-                    copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, solo, clk);
+                    copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far.direct_w, dep_mask, sl, solo, clk);
             }
 #else
-            copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, solo, clk);
+            copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far.direct_w, dep_mask, sl, solo, clk);
 #endif
             wave::set_priority(0);
             clk.lap(kPhCopyLevels);
@@ -2165,9 +2177,10 @@ __device__ inline void duo_consumer(DuoLds& D, const DecodeArgs& a)
             {
                 const uint8_t* const lits = reinterpret_cast<const uint8_t*>(S->lits);
                 const uint32_t q_idx = lit_f - F0, w_idx = span0 - g0 + la;
-                own_copy_simple(lits + q_idx, D.win + w_idx, nlit, nlit != 0u && nlit <= kOwnCopy);
-                if (wave::any(nlit > kOwnCopy)) {
-                    const uint32_t lmask = wave::half_ballot(nlit > kOwnCopy);
+                own_copy_simple(lits + q_idx, D.win + w_idx, nlit, wave::ballot_lt_k<kOwnCopy>(nlit - 1u));
+                const uint64_t long_w = wave::ballot_gt_k<kOwnCopy>(nlit);
+                if (long_w != 0ull) {
+                    const uint32_t lmask = wave::half_of(long_w);
                     const Team tl = make_team(lmask, sl);
                     const uint32_t l_src = wave::half_shfl(q_idx, tl.job), l_dst = wave::half_shfl(w_idx, tl.job);
                     const uint32_t l_len = wave::half_shfl(nlit, tl.job);
@@ -2184,11 +2197,11 @@ __device__ inline void duo_consumer(DuoLds& D, const DecodeArgs& a)
             store_far_sources(D.win, D.stage, job.out, far, plen, far_len, dst_idx);
             wave::sync();
             {
-                const bool plain_piece = (far_len == 0u || far_len == pattern) && dist >= plen && plen <= 32u;
-                if (!wave::any(plen != 0u && !far_direct && !plain_piece))
-                    copy_levels_plain(D.win, D.stage, plen, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, clk);
+                const uint64_t plain_w = (wave::ballot_eq0(far_len) | wave::ballot_eq(far_len, pattern)) & ~wave::ballot_lt(dist, plen) & wave::ballot_lt_k<33u>(plen);
+                if ((wave::ballot_ne0(plen) & ~far.direct_w & ~plain_w) == 0ull)
+                    copy_levels_plain(D.win, D.stage, plen, far_len, stage_off, src_idx, dst_idx, far.direct_w, dep_mask, sl, clk);
                 else
-                    copy_levels(D.win, D.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, true, clk);
+                    copy_levels(D.win, D.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far.direct_w, dep_mask, sl, true, clk);
             }
         }
         out_pos += round_bytes;                                         // (a round without bytes sends no step)

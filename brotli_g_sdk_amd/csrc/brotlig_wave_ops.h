@@ -26,6 +26,37 @@ __device__ __forceinline__ uint32_t lane_id_fresh()
 // v_cmp per call on top of the compare that produced the predicate; round 4, ~40 ballots per round)
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// Ballots of ONE comparison, written as the instruction they are (v_cmp into a scalar register pair; inactive lanes give 0).  The
+// compiler lowers the ballot of a compound predicate -- also one it has folded together itself, e.g. the ballot of n > 32 where n is a
+// select -- through a 0 / 1 register and a second compare: two vector-ALU instructions per question, on a kernel bound by the vector
+// ALU.  Compound questions are asked as scalar arithmetic on these masks instead (s_and / s_or / s_andn2).
+__device__ __forceinline__ uint64_t ballot_gt(uint32_t a, uint32_t b) { uint64_t m; asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ uint64_t ballot_lt(uint32_t a, uint32_t b) { return ballot_gt(b, a); }
+__device__ __forceinline__ uint64_t ballot_ne(uint32_t a, uint32_t b) { uint64_t m; asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+__device__ __forceinline__ uint64_t ballot_eq(uint32_t a, uint32_t b) { uint64_t m; asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
+template <uint32_t K> __device__ __forceinline__ uint64_t ballot_gt_k(uint32_t a)
+{
+    uint64_t m;
+    if constexpr (K <= 64u) asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "n"(K));        // inline constant
+    else asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(K));                            // (VOP3 takes no literal on gfx9: a scalar register)
+    return m;
+}
+template <uint32_t K> __device__ __forceinline__ uint64_t ballot_lt_k(uint32_t a)
+{
+    uint64_t m;
+    if constexpr (K <= 64u) asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "n"(K));        // inline constant
+    else asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(K));                            // (VOP3 takes no literal on gfx9: a scalar register)
+    return m;
+}
+template <uint32_t K> __device__ __forceinline__ uint64_t ballot_eq_k(uint32_t a)
+{
+    uint64_t m;
+    if constexpr (K <= 64u) asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "n"(K));        // inline constant
+    else asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(K));                            // (VOP3 takes no literal on gfx9: a scalar register)
+    return m;
+}
+__device__ __forceinline__ uint64_t ballot_ne0(uint32_t a) { uint64_t m; asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(m) : "v"(a)); return m; }
+__device__ __forceinline__ uint64_t ballot_eq0(uint32_t a) { uint64_t m; asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(m) : "v"(a)); return m; }
 // A lane mask (the same in every lane: a ballot, or scalar arithmetic on ballots) as a lane predicate: no instruction, the mask IS the
 // condition register.  Lets the compound questions of a loop be asked as s_and / s_andn2 on masks instead of per-lane logic.
 __device__ __forceinline__ bool from_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }

@@ -490,7 +490,7 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
             clk.lap(kPhLvLong);
 
             // -- 5b. LZ77 copies in dependency levels
-            copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far_direct, dep_mask, sl, false, clk);
+            copy_levels(L.win, L.stage, plen, dist, far_len, stage_off, src_idx, dst_idx, far.direct_w, dep_mask, sl, false, clk);
             clk.lap(kPhCopyLevels);
         }
 

@@ -20,6 +20,15 @@ inline uint64_t ballot64(bool p, SIM_SITE)
     return m;
 }
 inline bool any(bool p, SIM_SITE) { return ballot64(p, site) != 0; }
+inline uint64_t ballot_gt(uint32_t a, uint32_t b, SIM_SITE) { return ballot64(a > b, site); }
+inline uint64_t ballot_lt(uint32_t a, uint32_t b, SIM_SITE) { return ballot64(a < b, site); }
+inline uint64_t ballot_ne(uint32_t a, uint32_t b, SIM_SITE) { return ballot64(a != b, site); }
+inline uint64_t ballot_eq(uint32_t a, uint32_t b, SIM_SITE) { return ballot64(a == b, site); }
+template <uint32_t K> inline uint64_t ballot_gt_k(uint32_t a, SIM_SITE) { return ballot64(a > K, site); }
+template <uint32_t K> inline uint64_t ballot_lt_k(uint32_t a, SIM_SITE) { return ballot64(a < K, site); }
+template <uint32_t K> inline uint64_t ballot_eq_k(uint32_t a, SIM_SITE) { return ballot64(a == K, site); }
+inline uint64_t ballot_ne0(uint32_t a, SIM_SITE) { return ballot64(a != 0u, site); }
+inline uint64_t ballot_eq0(uint32_t a, SIM_SITE) { return ballot64(a == 0u, site); }
 inline bool from_mask(uint64_t m) { return ((m >> lane_id()) & 1u) != 0u; }
 inline uint32_t half_of(uint64_t m) { return (uint32_t)(m >> (lane_id() & 32u)); }
 inline uint32_t bcast(uint32_t v, uint32_t src, SIM_SITE)
