@@ -906,9 +906,9 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
 // EARLIER group's flush.  When the group does not fit behind what the window holds, the window slides: kHist .. kHist + 15
 // bytes of history are kept and brought down in one step, all reads before the writes.
 template <class G = GeoPair>
-__device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed, uint8_t* out, bool on, uint32_t gpos, uint32_t gend, uint32_t sl)
+__device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed, uint8_t* out, bool on, uint64_t on_w, uint32_t gpos, uint32_t gend, uint32_t sl)
 {
-    const uint64_t slide_w = (kAblate & kAblSlide) ? 0ull : wave::ballot64(on) & wave::ballot_gt(gend, view.win_base + G::kWin);
+    const uint64_t slide_w = (kAblate & kAblSlide) ? 0ull : on_w & wave::ballot_gt(gend, view.win_base + G::kWin);       // (on_w: `on` of every lane)
     const bool slide = wave::from_mask(slide_w);
     wave::sync();
     // (the two-piece and the three-piece forms are written out separately: with the third piece as a folded-away branch inside
@@ -962,6 +962,11 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
         view.win_base = nb;
     }
     wave::sync();
+}
+template <class G = GeoPair>
+__device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed, uint8_t* out, bool on, uint32_t gpos, uint32_t gend, uint32_t sl)
+{
+    flush_and_slide<G>(view, flushed, out, on, wave::ballot64(on), gpos, gend, sl);
 }
 
 // ---- stage: the LZ77 copies of a group in dependency levels (PageDecoder.cpp:219-232 / BrotliGCompute.hlsl:1401-1419).
@@ -1362,10 +1367,11 @@ __device__ __forceinline__ void store_far_sources(uint8_t* win, uint64_t* stage,
 // one popcount.  Returns the lanes (of the half) whose pieces own bytes of [psrc, src_end) inside the group and come
 // before me; everything below the group (page position gpos) is final.
 template <class Clock, class G = GeoPair>
-__device__ __forceinline__ uint32_t piece_dependencies(uint32_t* start_bits, uint8_t* start_cum, bool on, bool in_group, uint32_t first_rel, uint32_t gpos,
+__device__ __forceinline__ uint32_t piece_dependencies(uint32_t* start_bits, uint8_t* start_cum, bool on, uint64_t in_group_w, uint32_t first_rel, uint32_t gpos,
                                                         uint32_t psrc, uint32_t src_end, bool has_piece, uint32_t sl, Clock& clk)
 {
-    const uint32_t piece_mask = wave::half_ballot(in_group);
+    const uint32_t piece_mask = wave::half_of(in_group_w);              // (in_group_w: which lanes have a piece in the group)
+    const bool in_group = wave::from_mask(in_group_w);
     if (on && sl < G::kRoundMax / 32u) start_bits[sl] = 0u;
     wave::sync();
     if (in_group) atomicOr(&start_bits[first_rel >> 5], 1u << (first_rel & 31u));
@@ -1754,13 +1760,16 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
         // `dist` bytes back (its earlier bytes are final by then).
         const uint32_t ngroups = live ? (round_bytes + G::kRoundMax - 1u) / G::kRoundMax : 0u;
         const bool multi_group = wave::any(ngroups > 1u);
-        for (uint32_t g = 0; wave::any(g < ngroups); ++g) {
-            const bool on = g < ngroups;
+        const uint64_t okcmd_w = wave::ballot64(ok_cmd), cp_w = wave::ballot64(cp);     // (lane masks: see wave::ballot_gt)
+        for (uint32_t g = 0; ; ++g) {
+            const uint64_t on_w = wave::ballot_lt(g, ngroups);
+            if (on_w == 0ull) break;
+            const bool on = wave::from_mask(on_w);
             const uint32_t g0 = g * G::kRoundMax, g1 = on ? min_u32(round_bytes, g0 + G::kRoundMax) : g0;
             const uint32_t gpos = out_pos + g0;                         // page position of the group's first byte
 
             // -- 3b. flush the finished bytes, slide the window when the group does not fit
-            flush_and_slide<G>(view, flushed, job.out, on, gpos, out_pos + g1, sl);
+            flush_and_slide<G>(view, flushed, job.out, on, on_w, gpos, out_pos + g1, sl);
             clk.lap(kPhSlide);
             clk.count(kPhGroups, 1);
             clk.halves(kPhGroupHalves, on);
@@ -1768,13 +1777,27 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
 
             // -- 3c. my pieces in this group
             const uint32_t cs = rel0 + ins;                             // my copy starts here (round-relative)
-            const bool in_group = on && ok_cmd && rel0 < g1 && rel0 + tot > g0;
-            const uint32_t la = rel0 > g0 ? rel0 : g0, lb = cs < g1 ? cs : g1;
-            const uint32_t nlit = (in_group && lb > la) ? lb - la : 0u;     // my literal bytes in the group
-            const uint32_t lit_f = lit_a + (la - rel0);                 // consumption index of the first of them
-            const uint32_t ca = cs > g0 ? cs : g0, cb = rel0 + tot < g1 ? rel0 + tot : g1;
-            const uint32_t plen = (in_group && cp && cb > ca) ? cb - ca : 0u;       // my copy bytes in the group
-            const uint32_t pdst = out_pos + ca;                         // page position of the piece
+            uint64_t in_group_w;                                        // lanes with a piece in the group
+            uint32_t la, nlit, lit_f, plen, pdst;                       // my first byte in the group; my literal bytes in it and the consumption
+                                                                        // index of the first; my copy bytes in it and their page position
+            if (multi_group) {
+                in_group_w = on_w & okcmd_w & wave::ballot_lt(rel0, g1) & wave::ballot_gt(rel0 + tot, g0);
+                const bool in_group = wave::from_mask(in_group_w);
+                const uint32_t lb = cs < g1 ? cs : g1;
+                la = rel0 > g0 ? rel0 : g0;
+                nlit = (in_group && lb > la) ? lb - la : 0u;
+                lit_f = lit_a + (la - rel0);
+                const uint32_t ca = cs > g0 ? cs : g0, cb = rel0 + tot < g1 ? rel0 + tot : g1;
+                plen = (in_group && cp && cb > ca) ? cb - ca : 0u;
+                pdst = out_pos + ca;
+            } else {                                                    // the round is one group (nearly always): every command lies in it whole
+                in_group_w = on_w & okcmd_w;
+                la = rel0;
+                nlit = wave::from_mask(in_group_w) ? ins : 0u;
+                lit_f = lit_a;
+                plen = wave::from_mask(on_w & cp_w) ? copy : 0u;
+                pdst = copy_dst;
+            }
             const uint32_t psrc = pdst - dist;
             const uint32_t pattern = min_u32(plen, dist);
             const uint32_t src_end = psrc + pattern;
@@ -1804,7 +1827,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
             if (multi_group) { F0 = wave::half_sum(mine_before); F1 = F0 + wave::half_sum(nlit); }
             // exact dependencies of my copy piece: the pieces (of commands before me) that own bytes of its source range
             // inside this group; everything below the group is final
-            const uint32_t dep_mask = piece_dependencies<PhaseClock<kProf>, G>(L.start_bits, L.start_cum, on, in_group, (rel0 > g0 ? rel0 : g0) - g0, gpos,
+            const uint32_t dep_mask = piece_dependencies<PhaseClock<kProf>, G>(L.start_bits, L.start_cum, on, in_group_w, la - g0, gpos,
                                                          psrc, src_end, plen != 0u && !far_direct && !(kAblate & kAblDeps), sl, clk);
             clk.lap(kPhCopyFence);
 
@@ -2171,7 +2194,7 @@ __device__ inline void duo_consumer(DuoLds& D, const DecodeArgs& a)
             const FarSources far = fetch_far_sources(job.out, D.win, psrc - view.win_base, false, plen, psrc, far_len, sl);
             const bool far_direct = far.direct;
             const uint32_t stage_off = far.stage_off;
-            const uint32_t dep_mask = piece_dependencies<PhaseClock<false>, G>(D.start_bits, D.start_cum, on, in_group, (rel0 > g0 ? rel0 : g0) - g0, gpos,
+            const uint32_t dep_mask = piece_dependencies<PhaseClock<false>, G>(D.start_bits, D.start_cum, on, wave::ballot64(in_group), (rel0 > g0 ? rel0 : g0) - g0, gpos,
                                                                               psrc, src_end, plen != 0u && !far_direct, sl, clk);
             // literal runs: from the step's queue to their place in the window; then the slot goes back to the producer
             {

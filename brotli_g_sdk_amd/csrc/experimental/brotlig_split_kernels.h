@@ -451,7 +451,7 @@ __device__ inline void assemble_pages(AssembleWaveLds& W, const DecodeArgs& a)
                 if (nlit > 16u) le2 = load_u64u(lsrc + min_u32(16u, lclip));
                 if (nlit > 24u) le3 = load_u64u(lsrc + lclip);
             }
-            const uint32_t dep_mask = piece_dependencies(L.start_bits, L.start_cum, on, in_group, (rel0 > g0 ? rel0 : g0) - g0, gpos,
+            const uint32_t dep_mask = piece_dependencies<PhaseClock<false>>(L.start_bits, L.start_cum, on, wave::ballot64(in_group), (rel0 > g0 ? rel0 : g0) - g0, gpos,
                                                          psrc, src_end, plen != 0u && !(kAblate & kAblDeps), sl, clk);
             clk.lap(kPhCopyFence);
 
