@@ -424,7 +424,8 @@ __device__ __forceinline__ uint32_t mod_u16(uint32_t j, uint32_t d)
 // the last one, is harmless (same bytes to the same place).  BROTLIG_TUNE_CHUNKS says how many of the four are issued without
 // asking whether the piece is that long: each question is an exec-mask branch, each unconditional chunk an LDS access.
 #ifndef BROTLIG_TUNE_CHUNKS
-#define BROTLIG_TUNE_CHUNKS 2     // measured (round 3, 4 GiB): 0 / 1 / 2 -> mixed 434 / 442 / 444, text 439 / 451 / 449, records 449 / 468 / 473 GB/s
+#define BROTLIG_TUNE_CHUNKS 1     // measured (round 3, 4 GiB): 0 / 1 / 2 -> mixed 434 / 442 / 444, text 439 / 451 / 449, records 449 / 468 / 473 GB/s; round 4, once the
+                                  // questions had moved to the scalar unit, 1 against 2: mixed +0.9 %, text +1.0 %, records -0.3 %, samples16 +0.3 %
 #endif
 struct Chunks32 { uint64_t v0, v1, v2, v3; };
 #ifndef BROTLIG_TUNE_LIT_CHUNKS
@@ -918,7 +919,7 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
         const uint32_t e16 = gpos & ~15u;
         const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u;
         const bool f0 = on && p0 < e16, f1 = on && p1 < e16;
-        Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0;
+        Bytes16 a0, a1;         // (each stored under the condition it is loaded under: zeroing them is four v_mov apiece)
         if (f0) a0 = load16(view.win + (p0 - view.win_base));
         if (f1) a1 = load16(view.win + (p1 - view.win_base));
         if (f0) store16(out + p0, a0);
@@ -928,7 +929,7 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
         const uint32_t e16 = gpos & ~15u;
         const uint32_t p0 = flushed + 16u * sl, p1 = p0 + 512u, p2 = p0 + 1024u;
         const bool f0 = on && p0 < e16, f1 = on && p1 < e16, f2 = on && p2 < e16;
-        Bytes16 a0 = {0u, 0u, 0u, 0u}, a1 = a0, a2 = a0;
+        Bytes16 a0, a1, a2;
         if (f0) a0 = load16(view.win + (p0 - view.win_base));
         if (f1) a1 = load16(view.win + (p1 - view.win_base));
         if (f2) a2 = load16(view.win + (p2 - view.win_base));
@@ -942,7 +943,7 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
         const uint32_t shift = nb - view.win_base, count = shift ? gpos - nb : 0u;
         if constexpr (G::kSlidePieces <= 2u) {
             const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl;
-            Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0;
+            Bytes16 m0, m1;
             if (i0 < count) m0 = load16(view.win + shift + i0);
             if (i1 < count) m1 = load16(view.win + shift + i1);
             wave::sync();
@@ -950,7 +951,7 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
             if (i1 < count) store16(view.win + i1, m1);
         } else {
             const uint32_t i0 = 16u * sl, i1 = 512u + 16u * sl, i2 = 1024u + 16u * sl;
-            Bytes16 m0 = {0u, 0u, 0u, 0u}, m1 = m0, m2 = m0;
+            Bytes16 m0, m1, m2;
             if (i0 < count) m0 = load16(view.win + shift + i0);
             if (i1 < count) m1 = load16(view.win + shift + i1);
             if (i2 < count) m2 = load16(view.win + shift + i2);
@@ -1299,7 +1300,7 @@ __device__ __forceinline__ FarSources fetch_far_sources(const uint8_t* out, cons
     f.stage_off = 0;
     if (f.any_staged) f.stage_off = wave::half_scan_incl(stage_len) - stage_len;
     f.teams = f.any_staged && (staged_w & wave::ballot_gt_k<kShortCopy>(far_len)) != 0ull;
-    f.fe0 = f.fe1 = f.fe2 = f.fe3 = f.te0 = f.te1 = 0;
+    f.fe0 = f.fe1 = f.fe2 = f.fe3 = f.te0 = f.te1 = 0;       // (leaving these unset saves six moves a group and costs 21 spilled values: measured, not done)
     f.team = Team{5u, 0u, 0u, false};
     f.t_src = f.t_len = f.t_stage = 0;
     const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
