@@ -17,7 +17,8 @@ python bench.py --workload samples16 --no-cpu-baseline > "$out/bench_samples16.j
 python bench.py --workload records --no-cpu-baseline > "$out/bench_records.json" 2>> "$out/bench.err"
 # every page distinct (about 1 GB of compressed data, beyond the 256 MiB Infinity Cache): does the tiling of 256 pages matter?
 python bench.py --distinct 4096 --no-cpu-baseline > "$out/bench_distinct4096.json" 2>> "$out/bench.err"
-python profiles/tools/latency.py > "$out/latency.json" 2>> "$out/bench.err"
+python profiles/tools/latency.py auto one_wavefront two_wavefronts > "$out/latency.json" 2>> "$out/bench.err"
+for m in one_wavefront two_wavefronts; do python profiles/tools/page_latency.py $m 2>> "$out/bench.err" | grep "^{"; done > "$out/page_latency.jsonl"
 python profiles/tools/streamer_bench.py > "$out/streamer_bench.json" 2>> "$out/bench.err"
 python profiles/tools/cpu_decode_bench.py > "$out/cpu_decode.json" 2>> "$out/bench.err"
 for k in "mixed 16" "text 16" "runs 16" "bc3 64" "samples16 16" "records 16"; do python profiles/phase_profile.py $k; done > "$out/phase_profile.jsonl" 2>> "$out/bench.err"
@@ -29,6 +30,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o f -- python "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$out/pmc_sq1" -o f -- python "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/pmc_sq1.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d "$out/pmc_sq2" -o f -- python "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/pmc_sq2.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --output-format csv -d "$out/pmc_sq3" -o f -- python "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/pmc_sq3.log" 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/pmc_tcc" -o f -- python "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-alt-parse > "$out/pmc_tcc.log" 2>&1
 # keep only what the summariser needs (the merge-back limit is 64 MiB)
 find "$out" -name '*_kernel_trace.csv' -size +8M -delete

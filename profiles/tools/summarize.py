@@ -14,6 +14,8 @@ for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16"
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, pre + name + ".json")
 shutil.copy(os.path.join(src, "phase_profile.jsonl"), pre + "phase_profile.jsonl")
+if os.path.exists(os.path.join(src, "page_latency.jsonl")):
+    shutil.copy(os.path.join(src, "page_latency.jsonl"), pre + "page_latency.jsonl")
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
@@ -69,7 +71,7 @@ except Exception as e:
 json.dump(j, open(pre + "hbm_traffic.json", "w"), indent=1)
 # SQ counters (two passes), decode kernel only, averaged over its dispatches
 sq = {}
-for sub in ("pmc_sq1", "pmc_sq2"):
+for sub in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):
     ps = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
     if not ps: continue
     acc = {}
@@ -86,5 +88,11 @@ if sq:
         if "SQ_WAVE_CYCLES" in sq and "SQ_ACTIVE_INST_VALU" in sq:
             f.write("\nVALU-active / wave cycles: %.3f; wait-any / wave cycles: %.3f; VALU instructions per decompressed GiB: %.3g\n" % (
                 sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], sq.get("SQ_WAIT_ANY", 0) / sq["SQ_WAVE_CYCLES"], sq.get("SQ_INSTS_VALU", 0) / 4.0))
+        if "GRBM_GUI_ACTIVE" in sq and "SQ_ACTIVE_INST_VALU" in sq:
+            # rocprof's derived VALUBusy / scalar / LDS equivalents: quad-cycles of the arbiter per CU-cycle (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+            cu_cycles = sq["GRBM_GUI_ACTIVE"] / 8.0 * 256.0
+            f.write("\nPipe occupancy (quad-cycles / (cycles x 256 CUs)): vector ALU %.3f, scalar %.3f, LDS %.3f; active lanes per vector instruction %.3f\n" % (
+                sq["SQ_ACTIVE_INST_VALU"] / cu_cycles, sq.get("SQ_ACTIVE_INST_SCA", 0) / cu_cycles, sq.get("SQ_ACTIVE_INST_LDS", 0) / cu_cycles,
+                sq.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * sq["SQ_ACTIVE_INST_VALU"])))
 print(json.dumps({"decode_ms_rocprof": dec_avg, "decode_ms_bench": bench["roofline"]["kernel_ms"],
                   "fetch_GB": fetch * 1024 / 1e9, "write_GB": write * 1024 / 1e9, "alg_GB": alg / 1e9}))
