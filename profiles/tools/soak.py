@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak run on the MI355X box: the generators of tests/test_gpu_differential.py over many more seeds (plain and
 pre-conditioned streams against the bytes they were encoded from, damaged streams next to valid ones).
-  python profiles/tools/soak.py [first_seed] [n_plain] [n_precon] [n_corrupt]"""
+  python profiles/tools/soak.py [first_seed] [n_plain] [n_precon] [n_corrupt] [mode]
+mode: 0 = the kernel the batch size selects (these batches: two wavefronts per page), 1 = one wavefront per one or two pages, 2 = two wavefronts per page."""
 import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,6 +15,8 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 n_plain = int(sys.argv[2]) if len(sys.argv) > 2 else 1600
 n_precon = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 n_corrupt = int(sys.argv[4]) if len(sys.argv) > 4 else 400
+mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+api.DebugSetDecodeMode(mode)
 t0 = time.time(); bad = []
 B = 80
 for c in range(first, first + n_plain, B):
@@ -53,5 +56,5 @@ for c in range(first, first + n_corrupt, 40):
         statuses["refused"] = statuses.get("refused", 0) + 1
     out, _ = api.DecodeGPU(valid[0])
     if not np.array_equal(out, vref): bad.append(("valid-after-corrupt", c))
-print(json.dumps({"first_seed": first, "plain": n_plain, "precon": n_precon, "corrupt": n_corrupt, "failures": bad[:20], "n_failures": len(bad),
+print(json.dumps({"decode_mode": mode, "first_seed": first, "plain": n_plain, "precon": n_precon, "corrupt": n_corrupt, "failures": bad[:20], "n_failures": len(bad),
                   "corrupt_batch_statuses": {str(k): v for k, v in statuses.items()}, "seconds": round(time.time() - t0, 1)}))
