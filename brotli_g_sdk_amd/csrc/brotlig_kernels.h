@@ -977,6 +977,9 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
 // level without long pieces runs one lane per piece; otherwise the ready pieces share the 32 lanes as teams, 8 bytes per
 // lane per step.  Overlapping copies replay their pattern modulo the distance, so a copy never waits for itself.
 // Pieces with `far_direct` went from registers straight to their place and take no part.
+#ifndef BROTLIG_TUNE_POW2_OVERLAP
+#define BROTLIG_TUNE_POW2_OVERLAP 1
+#endif
 #ifndef BROTLIG_TUNE_MASK_LEVELS
 #define BROTLIG_TUNE_MASK_LEVELS 1
 #endif
@@ -1055,6 +1058,11 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
     const bool simple = wave::from_mask(simple_w);
     const uint64_t long_w = (simple_w & wave::ballot_gt_k<kOwnCopy>(plen)) | (~simple_w & wave::ballot_gt_k<kShortCopy>(plen));
     const uint64_t ge8_w = wave::ballot_gt_k<7u>(plen), gt32_w = wave::ballot_gt_k<32u>(plen);
+#if BROTLIG_TUNE_POW2_OVERLAP
+    // self-overlapping pieces with a period of 1, 2 or 4 bytes whose pattern lies in one place (asked once per group, and only when there is a
+    // piece that overlaps itself at all)
+    const uint64_t pow2_dist_w = (~simple_w & todo_w) != 0ull ? whole_w & ~simple_w & wave::ballot_lt_k<5u>(dist) & ~wave::ballot_eq_k<3u>(dist) : 0ull;
+#endif
     while (todo_w != 0ull) {
         clk.count(kPhLevels, 1);
         clk.halves(kPhLevelHalves, todo != 0u);
@@ -1086,7 +1094,6 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
 #endif
 #if BROTLIG_TUNE_MASK_LEVELS
             const uint64_t a_w = (kAblate & kAblOwnLane) ? 0ull : ready_w & simple_w, b_w = (kAblate & kAblOverlap) ? 0ull : ready_w & ~simple_w;
-            const bool lane_b = wave::from_mask(b_w);
             if (wave::from_mask(a_w & ge8_w)) {
                 const Chunks32 c = load_chunks32(sp, plen, clip8);
                 store_chunks32(dp, c, plen, clip8);
@@ -1122,7 +1129,40 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
                 }
             }
             clk.lap(kPhLvShort);
-#if BROTLIG_TUNE_MASK_LEVELS
+#if BROTLIG_TUNE_MASK_LEVELS && BROTLIG_TUNE_POW2_OVERLAP
+            // Periods of 1, 2 and 4 bytes (a repeated byte, 16-bit sample, 32-bit word: most self-overlapping pieces of sampled data; here
+            // the piece is at most 32 bytes, longer ones run in teams): the pattern as ONE 8-byte word whose halves are alike, stored at 0 / 8 /
+            // 16 and, rotated to its phase, at plen - 8.  Nothing the piece wrote is read back: no LDS round trip per chunk.
+            uint64_t rest_w = b_w;
+            {
+                const uint64_t pow2_w = b_w & pow2_dist_w;
+                if (pow2_w != 0ull) {
+                    if (wave::from_mask(pow2_w)) {
+                        // (everything here depends on an opaque zero: otherwise the loop-invariant part -- phase, addresses, comparisons -- is
+                        // hoisted in front of the level loop, paid by every group and kept in registers across the levels: text -2 %)
+                        const uint32_t z = wave::opaque_zero();
+                        const uint32_t d = dist | z, n = plen | z, c8 = n - 8u;
+                        uint8_t* const q = dp + z;
+                        uint32_t x;
+                        __builtin_memcpy(&x, sp + z, 4);
+                        const uint32_t w = d == 4u ? x : d == 2u ? (x & 0xFFFFu) * 0x00010001u : (x & 0xFFu) * 0x01010101u;
+                        const uint32_t ph = 8u * (c8 & (d - 1u));                  // phase of the chunk that ends the piece
+                        const uint32_t wt = ph ? (w >> ph) | (w << (32u - ph)) : w;
+                        const uint64_t v = (uint64_t)w | ((uint64_t)w << 32), vt = (uint64_t)wt | ((uint64_t)wt << 32);
+                        if (n >= 8u) {
+                            __builtin_memcpy(q, &v, 8);
+                            if (n > 8u) __builtin_memcpy(q + c8, &vt, 8);
+                            if (n >= 16u) __builtin_memcpy(q + 8u, &v, 8);
+                            if (n >= 24u) __builtin_memcpy(q + 16u, &v, 8);
+                        } else store_bytes(q, v, n);
+                    }
+                    rest_w &= ~pow2_w;
+                }
+            }
+            const bool lane_b = wave::from_mask(rest_w);
+            if (rest_w != 0ull) {
+#elif BROTLIG_TUNE_MASK_LEVELS
+            const bool lane_b = wave::from_mask(b_w);
             if (b_w != 0ull) {
 #else
             if (wave::any(lane_b)) {

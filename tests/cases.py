@@ -38,7 +38,24 @@ def plain_cases():
         ("long_matches", lambda: np.tile(D.random_bytes(5000, 17), 40)[:N], {}),
         ("period_1_2_3", lambda: np.concatenate([np.full(30000, 7, np.uint8), np.tile(np.array([1, 2], np.uint8), 20000),
                                                  np.tile(np.array([9, 8, 7], np.uint8), 15000)]), {}),
+        # short self-overlapping copies of every period 1..9 and every length 3..32, noise between them: the copy levels lay down periods of
+        # 1, 2 and 4 bytes as one rotated 8-byte word (round 4), the others forward from their own output
+        ("short_periodic_runs", short_periodic_runs, {}),
+        ("short_periodic_runs_greedy", short_periodic_runs, dict(flags=E.NO_LAZY)),
+        ("periodic_runs_to_40", lambda: short_periodic_runs(41), {}),       # with pieces above 32 bytes among them: those levels run in teams
     ]
+
+
+def short_periodic_runs(length_end=33):
+    rng = np.random.default_rng(404)
+    parts = []
+    for rep in range(6):
+        for period in (1, 2, 4, 3, 8, 5, 2, 1, 4, 6, 7, 9):
+            for length in range(3, length_end):
+                pat = rng.integers(0, 256, period, dtype=np.uint8)
+                parts.append(rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8))       # noise: literals, and an odd alignment
+                parts.append(np.tile(pat, (period + length) // period + 1)[:period + length])      # the pattern, then `length` bytes of its repeat
+    return np.concatenate(parts)
 
 
 def skewed(n, seed):
