@@ -1230,6 +1230,22 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
         const uint8_t* t_base = t_far ? t_stage : t_win;
         const bool overlap = t_dist < t_len;
         clk.lap(kPhLvShort);
+#if BROTLIG_TUNE_POW2_OVERLAP
+        // Every served piece a run with a period that divides 8 (a repeated byte, 16-bit sample, 32 / 64-bit word; pattern in one place): every
+        // 8-byte chunk of it is the same word -- read once, stored by the team, no remainder per chunk (byte runs: config 2).
+        const uint64_t act_w = wave::ballot64(act);
+        const uint64_t p8_w = act_w & wave::ballot_lt(t_dist, t_len) & wave::ballot_lt_k<9u>(t_dist) & wave::ballot_eq0(t_dist & (t_dist - 1u)) &
+                              (wave::ballot_eq0(t_far) | wave::ballot_eq(t_far, t_pat));
+        if (act_w != 0ull && p8_w == act_w) {
+            uint64_t v = 0;
+            if (act) v = pattern_source8(t_base, t_dist, 0u);
+            for (uint32_t c = t.member; wave::any(act && 8u * c < t_len); c += 1u << t.log2_size) {
+                const uint32_t j = 8u * c;
+                if (act && j < t_len) store_bytes(t_out + j, v, t_len - j);
+            }
+            wave::sync();
+        } else
+#endif
         for (uint32_t c = t.member; wave::any(act && 8u * c < t_len); c += 1u << t.log2_size) {
             const uint32_t j = 8u * c;
             if (act && j < t_len) {
