@@ -980,9 +980,6 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
 #ifndef BROTLIG_TUNE_POW2_OVERLAP
 #define BROTLIG_TUNE_POW2_OVERLAP 1
 #endif
-#ifndef BROTLIG_TUNE_MASK_LEVELS
-#define BROTLIG_TUNE_MASK_LEVELS 1
-#endif
 #ifndef BROTLIG_TUNE_PLAIN_LEVELS
 #define BROTLIG_TUNE_PLAIN_LEVELS 1
 #endif
@@ -997,7 +994,6 @@ __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* 
     const uint32_t clip8 = plen >= 8u ? plen - 8u : 0u;
     const uint8_t* const sp = far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx;
     uint8_t* const dp = win + dst_idx;
-#if BROTLIG_TUNE_MASK_LEVELS
     // The level loop's questions as wave-wide lane masks in scalar registers (wave::from_mask turns a mask back into a lane predicate
     // without an instruction): the ballot of a COMPOUND predicate goes through a 0 / 1 register and a second compare.
     uint64_t todo_w = wave::ballot_ne0(plen) & ~direct_w;
@@ -1018,26 +1014,6 @@ __device__ __forceinline__ void copy_levels_plain(uint8_t* win, const uint64_t* 
         wave::sync();
     }
     (void)sl;
-#else
-    uint32_t todo = wave::half_of(wave::ballot_ne0(plen) & ~direct_w);
-    while (wave::any(todo != 0u)) {
-        clk.count(kPhLevels, 1);
-        clk.halves(kPhLevelHalves, todo != 0u);
-        const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
-        const uint32_t ready_mask = wave::half_ballot(ready);
-        if (ready) {
-            if (plen >= 8u) {
-                const Chunks32 c = load_chunks32(sp, plen, clip8);
-                store_chunks32(dp, c, plen, clip8);
-            } else {
-                store_bytes(dp, load_u64u(sp), plen);
-            }
-        }
-        clk.lap(kPhLvShort);
-        todo &= ~ready_mask;
-        wave::sync();
-    }
-#endif
 }
 
 template <class Clock>
@@ -1049,7 +1025,6 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
     const uint32_t packed = plen | (far_len << 11) | ((stage_off >> 3) << 22);
     // simple piece: pattern in one place (window or staging area) and no chunk of a 32-byte batch reads
     // what an earlier chunk of the batch wrote
-#if BROTLIG_TUNE_MASK_LEVELS
     // (the questions of the level loop as wave-wide lane masks in scalar registers, see copy_levels_plain)
     uint64_t todo_w = (kAblate & kAblLevels) ? 0ull : wave::ballot_ne0(plen) & ~direct_w;
     uint32_t todo = wave::half_of(todo_w);
@@ -1070,16 +1045,6 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
         const bool ready = wave::from_mask(ready_w);
         const uint32_t ready_mask = wave::half_of(ready_w);
         if ((kAblate & kAblTeams) || (ready_w & long_w) == 0ull) {
-#else
-    const bool simple = (far_len == 0u || far_len == pattern) && (dist >= 32u || dist >= plen);
-    uint32_t todo = (kAblate & kAblLevels) ? 0u : wave::half_of(wave::ballot_ne0(plen) & ~direct_w);
-    while (wave::any(todo != 0u)) {
-        clk.count(kPhLevels, 1);
-        clk.halves(kPhLevelHalves, todo != 0u);
-        const bool ready = ((todo >> sl) & 1u) != 0u && (todo & dep_mask) == 0u;
-        const uint32_t ready_mask = wave::half_ballot(ready);
-        if ((kAblate & kAblTeams) || !wave::any(ready && (plen > (simple ? kOwnCopy : kShortCopy)))) {
-#endif
             // Own-lane copies.  The usual piece (pattern in one place; distance >= 32 or no overlap
             // with itself) moves in batches of four 8-byte chunks, loads before stores, at offsets
             // clipped to plen - 8: within a batch no chunk reads what an earlier chunk of the batch
@@ -1087,12 +1052,7 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             // has another ready piece inside its source).
             const uint8_t* sp = far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx;
             uint8_t* dp = win + dst_idx;
-#if BROTLIG_TUNE_MASK_LEVELS
             const bool whole = wave::from_mask(whole_w);
-#else
-            const bool whole = far_len == 0u || far_len == pattern;
-#endif
-#if BROTLIG_TUNE_MASK_LEVELS
             const uint64_t a_w = (kAblate & kAblOwnLane) ? 0ull : ready_w & simple_w, b_w = (kAblate & kAblOverlap) ? 0ull : ready_w & ~simple_w;
             if (wave::from_mask(a_w & ge8_w)) {
                 const Chunks32 c = load_chunks32(sp, plen, clip8);
@@ -1102,20 +1062,6 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             uint64_t more_w = a_w & gt32_w;
             for (uint32_t o = 32u; more_w != 0ull; o += 32u, more_w &= wave::ballot_gt(plen, o)) {      // further batches: bytes o .. min(o + 32, plen) - 1
                 if (wave::from_mask(more_w)) {
-#else
-            const bool lane_a = ready && simple && !(kAblate & kAblOwnLane);
-            const bool lane_b = ready && !simple && !(kAblate & kAblOverlap);
-            if (lane_a) {
-                if (plen >= 8u) {
-                    const Chunks32 c = load_chunks32(sp, plen, clip8);
-                    store_chunks32(dp, c, plen, clip8);
-                } else {
-                    store_bytes(dp, load_u64u(sp), plen);
-                }
-            }
-            for (uint32_t o = 32u; wave::any(lane_a && plen > o); o += 32u) {      // further batches: bytes o .. min(o + 32, plen) - 1
-                if (lane_a && plen > o) {
-#endif
                     const uint32_t c0 = min_u32(o, clip8), c1 = min_u32(o + 8u, clip8), c2 = min_u32(o + 16u, clip8), c3 = min_u32(o + 24u, clip8);
                     uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
                     v0 = load_u64u(sp + c0);
@@ -1129,7 +1075,7 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
                 }
             }
             clk.lap(kPhLvShort);
-#if BROTLIG_TUNE_MASK_LEVELS && BROTLIG_TUNE_POW2_OVERLAP
+#if BROTLIG_TUNE_POW2_OVERLAP
             // Periods of 1, 2 and 4 bytes (a repeated byte, 16-bit sample, 32-bit word: most self-overlapping pieces of sampled data; here
             // the piece is at most 32 bytes, longer ones run in teams): the pattern as ONE 8-byte word whose halves are alike, stored at 0 / 8 /
             // 16 and, rotated to its phase, at plen - 8.  Nothing the piece wrote is read back: no LDS round trip per chunk.
@@ -1161,11 +1107,9 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             }
             const bool lane_b = wave::from_mask(rest_w);
             if (rest_w != 0ull) {
-#elif BROTLIG_TUNE_MASK_LEVELS
+#else
             const bool lane_b = wave::from_mask(b_w);
             if (b_w != 0ull) {
-#else
-            if (wave::any(lane_b)) {
 #endif
                 // The rest.  Self-overlapping pieces with a distance below 32 are copied forward in
                 // 8-byte chunks from `dd` bytes back, each chunk reading what its predecessors wrote
@@ -1269,9 +1213,7 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
         clk.lap(kPhLvBytes);
         }
         todo &= ~ready_mask;
-#if BROTLIG_TUNE_MASK_LEVELS
         todo_w &= ~ready_w;
-#endif
         wave::sync();
     }
 }
