@@ -113,16 +113,9 @@ def _precon_words(fmt, w, h, mips=1, swizzle=0, aligned=0, pitch=None, widths=No
 
 
 def _sim():
-    import subprocess
-    sim_dir = os.path.join(os.path.dirname(__file__), "sim")
-    csrc = os.path.join(os.path.dirname(__file__), "..", "brotli_g_sdk_amd", "csrc")
-    so = os.path.join(sim_dir, "libbrotlig_sim.so")
-    srcs = [os.path.join(sim_dir, f) for f in ("sim_decode.cpp", "sim_runtime.cpp")]
-    deps = srcs + [os.path.join(sim_dir, f) for f in ("sim_runtime.h", "brotlig_wave_ops.h")] + \
-        [os.path.join(csrc, f) for f in ("brotlig_kernels.h", "brotlig_format.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-I", sim_dir, "-I", csrc, "-o", so] + srcs)
-    return ctypes.CDLL(so)
+    # one builder for the simulator library (flags, dependency list, atomic replace under pytest-xdist): tests/test_sim_decode.py
+    from test_sim_decode import build_sim
+    return build_sim("libbrotlig_sim.so")
 
 
 def test_struct_field_order_matches_datastream_h():
