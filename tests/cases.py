@@ -75,6 +75,9 @@ def precon_cases():
         ("bc3_aligned_nodelta", 3, 64, 64, 2, 1, 0, 1, 0),
         ("bc3_mips6_aligned", 3, 37, 21, 6, 1, 1, 1, 0),
         ("bc5_pitch_pad", 5, 33, 17, 1, 1, 1, 0, 33 * 16 + 7),
+        ("bc3_wide_swz_mips2", 3, 320, 6, 2, 1, 1, 0, 0),         # several 128-block steps per row pair, the last one partial (quad de-conditioning)
+        ("bc1_mips_6_3_2", 1, 6, 6, 3, 1, 1, 0, 0),               # an even mip behind an odd one: its rows start 8 bytes off a 16-byte boundary
+        ("bc4_swz_200x2", 4, 200, 2, 1, 1, 0, 0, 0),
     ]:
         pre = dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=swz, delta=delta,
                    pitch_d3d12_aligned=aligned, pitch_bytes=pitch)
