@@ -1,8 +1,7 @@
 mkdir -p gpurun_out/dc
-for v in noquads base; do BROTLIG_HIP_SO=$(pwd)/build/abv/lib_$v.so timeout 200 python bench.py --workload bc3 --streams 256 --no-cpu-baseline --no-alt-parse --steps 5 --warmup 2 2>/dev/null | python -c "
+for v in base y8 y128 wg16 y4wg4; do BROTLIG_HIP_SO=$(pwd)/build/abv/lib_$v.so timeout 200 python bench.py --workload bc3 --streams 256 --no-cpu-baseline --no-alt-parse --steps 5 --warmup 2 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
         d = json.loads(l); print('config4 $v', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['bit_exact'])
 "; done
-timeout 600 python -m pytest tests/test_gpu_decode.py tests/test_gpu_differential.py -m gpu -x -q -k "precon or texture or bc3 or mixed_plain" 2>&1 | tail -2
