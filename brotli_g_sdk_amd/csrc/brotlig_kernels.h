@@ -2343,24 +2343,36 @@ __device__ __forceinline__ void dc_gather_block(const uint8_t* cond, const DcTab
     }
 }
 
-__global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
+// One texture, kItems work items per lane and step: ALL their loads are issued before the first is used.  The gather is bound by
+// the bytes it has in flight: reads alone take 2.04 ms of the kernel's 2.90 (4 GiB of BC3; stores alone 0.77 ms), a wavefront holds
+// 7 loads (1 KiB) per item, and at the loaded latency of ~4 us 32 wavefronts x 1 KiB per compute unit are 2.1 TB/s.
+#ifndef BROTLIG_TUNE_DC_ITEMS
+#define BROTLIG_TUNE_DC_ITEMS 2
+#endif
+template <uint32_t kSizes, uint32_t kNumSub, uint32_t kItems>
+__device__ __forceinline__ void dc_texture(const DcTable* __restrict__ tp, const uint8_t* __restrict__ cond, uint8_t* __restrict__ tex, uint32_t s, uint32_t tid, uint32_t nthreads)
 {
-    if (a.status[2] == 0u) return;                                      // no preconditioned stream in this batch
-    const uint32_t nthreads = gridDim.x * blockDim.x;
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    for (uint32_t s = blockIdx.y; s < a.num_streams; s += gridDim.y) {
-        const DcTable& t = a.dc[s];
-        if (!t.precon) continue;
-        const uint64_t base = a.streams[s].out_offset;
-        const uint8_t* cond = a.scratch + base;
-        uint8_t* tex = a.out + base;
-        const uint32_t bb = t.block_bytes, items = t.item_prefix[t.num_mips];
-        // Streams decoded side by side (blockIdx.y) start at different tiles: textures of the same size sit
-        // at power-of-two distances in memory, and walking them in step would hit the same HBM channels.
-        const uint32_t ntiles = items >> 6;
-        const uint32_t rot = ntiles ? ((s * 2654435761u) >> 8) % ntiles * 64u : 0u;
-        for (uint32_t item0 = tid; item0 < items; item0 += nthreads) {
-            const uint32_t item = item0 + rot < items ? item0 + rot : item0 + rot - items;
+    // (__restrict__: the table is not what the stores below write to -- without it every table word is re-read with a vector load, and waited
+    // for, in front of the load it is the address of)
+    const DcTable& t = *tp;
+    const uint32_t bb = t.block_bytes, items = t.item_prefix[t.num_mips];
+    uint32_t sso[kNumSub];
+#pragma unroll
+    for (uint32_t sub = 0; sub < kNumSub; ++sub) sso[sub] = t.sub_stream_off[sub];
+    // Streams decoded side by side (blockIdx.y) start at different tiles: textures of the same size sit
+    // at power-of-two distances in memory, and walking them in step would hit the same HBM channels.
+    const uint32_t ntiles = items >> 6;
+    const uint32_t rot = ntiles ? ((s * 2654435761u) >> 8) % ntiles * 64u : 0u;
+    for (uint32_t item0 = tid; item0 < items; item0 += kItems * nthreads) {
+        uint8_t* dst[kItems];
+        uint32_t nbytes[kItems], gblock[kItems];
+        bool valid[kItems], loads[kItems];
+#pragma unroll
+        for (uint32_t u = 0; u < kItems; ++u) {
+            const uint32_t it = item0 + u * nthreads;
+            valid[u] = false; loads[u] = false; dst[u] = tex; nbytes[u] = 0; gblock[u] = 0;
+            if (it >= items) continue;
+            const uint32_t item = it + rot < items ? it + rot : it + rot - items;
             // a wavefront owns one tile (64 consecutive items; nthreads is a multiple of 64): the mip and tile
             // coordinates are wave-uniform and go to the scalar unit
             const uint32_t tile_item = wave::uniform(item & ~63u), l = item & 63u;
@@ -2372,9 +2384,9 @@ __global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
             const uint32_t tr = tile / tiles_x, tc = tile - tr * tiles_x;
             const uint32_t row = 2u * tr + ((l >> 1) & 1u), col = 32u * tc + 2u * (l >> 2) + (l & 1u);
             if (row >= H || col >= per_row) continue;
-            uint8_t* dst = tex + t.mip_off_bytes[m] + row * pitch + col * bb;
-            const uint32_t nbytes = min_u32(bb, pitch - col * bb);
-            uint64_t lo = 0, hi = 0;
+            valid[u] = true;
+            dst[u] = tex + t.mip_off_bytes[m] + row * pitch + col * bb;
+            nbytes[u] = min_u32(bb, pitch - col * bb);
             if (col < W) {
                 // inverse of the 2x2 de-swizzle (PageDecoder.cpp:416-436): texture (row, col) -> block index
                 uint32_t block = row * W + col;
@@ -2386,22 +2398,62 @@ __global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
                     const uint32_t wrap = x >= effW ? 1u : 0u;
                     block = (2u * (row >> 1) + wrap) * W + (x - (wrap ? effW : 0u));
                 }
-                const uint32_t gblock = t.mip_off_blocks[m] + block;
-                // per-format instantiations: sub-block sizes known at compile time, so that all of a block's
-                // loads are issued back to back and waited for once
-                switch (t.format) {
-                case 1: dc_gather_block<0x422u, 3u>(cond, t, gblock, lo, hi); break;
-                case 2: dc_gather_block<0x4228u, 4u>(cond, t, gblock, lo, hi); break;
-                case 3: dc_gather_block<0x422611u, 6u>(cond, t, gblock, lo, hi); break;
-                case 4: dc_gather_block<0x611u, 3u>(cond, t, gblock, lo, hi); break;
-                case 5: dc_gather_block<0x611611u, 6u>(cond, t, gblock, lo, hi); break;
-                default: dc_gather_block<0x1u, 1u>(cond, t, gblock, lo, hi); break;
-                }
+                gblock[u] = t.mip_off_blocks[m] + block;
+                loads[u] = true;
             }
-            const bool aligned = ((uint64_t)(uintptr_t)dst & (uint64_t)(bb - 1u)) == 0u;
-            if (nbytes == 16u && aligned) { uint64_t v[2] = {lo, hi}; __builtin_memcpy(__builtin_assume_aligned(dst, 16), v, 16); }
-            else if (nbytes == 8u && bb == 8u && aligned) __builtin_memcpy(__builtin_assume_aligned(dst, 8), &lo, 8);
-            else for (uint32_t i = 0; i < nbytes; ++i) dst[i] = (uint8_t)((i < 8u ? lo >> (8u * i) : hi >> (8u * (i - 8u))));
+        }
+        // sub-block sizes known at compile time: every load of every item is issued here, back to back, and waited for once
+        uint64_t v[kItems][kNumSub];
+#pragma unroll
+        for (uint32_t u = 0; u < kItems; ++u) {
+#pragma unroll
+            for (uint32_t sub = 0; sub < kNumSub; ++sub) {
+                const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
+                v[u][sub] = dc_load_sub(cond + sso[sub] + gblock[u] * sz, sz);     // (unconditional -- a lane without a block reads block 0 and drops
+                                                                                    // it: a branch per load keeps the loads from being in flight together)
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kItems; ++u) {
+            if (!valid[u]) continue;
+            uint64_t lo = 0, hi = 0;
+            uint32_t off = 0;
+#pragma unroll
+            for (uint32_t sub = 0; sub < kNumSub; ++sub) {
+                const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
+                if (off < 8u) { lo |= v[u][sub] << (8u * off); if (off + sz > 8u) hi |= v[u][sub] >> (8u * (8u - off)); }
+                else hi |= v[u][sub] << (8u * (off - 8u));
+                off += sz;
+            }
+            if (!loads[u]) { lo = 0; hi = 0; }                                  // row-pitch padding
+            uint8_t* const d = dst[u];
+            const bool aligned = ((uint64_t)(uintptr_t)d & (uint64_t)(bb - 1u)) == 0u;
+            if (nbytes[u] == 16u && aligned) { uint64_t q[2] = {lo, hi}; __builtin_memcpy(__builtin_assume_aligned(d, 16), q, 16); }
+            else if (nbytes[u] == 8u && bb == 8u && aligned) __builtin_memcpy(__builtin_assume_aligned(d, 8), &lo, 8);
+            else for (uint32_t i = 0; i < nbytes[u]; ++i) d[i] = (uint8_t)((i < 8u ? lo >> (8u * i) : hi >> (8u * (i - 8u))));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
+{
+    if (a.status[2] == 0u) return;                                      // no preconditioned stream in this batch
+    const uint32_t nthreads = gridDim.x * blockDim.x;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t s = blockIdx.y; s < a.num_streams; s += gridDim.y) {
+        const DcTable& t = a.dc[s];
+        if (!t.precon) continue;
+        const uint64_t base = a.streams[s].out_offset;
+        const uint8_t* cond = a.scratch + base;
+        uint8_t* tex = a.out + base;
+        // per-format instantiations (sub-block sizes, four bits each, first sub-block lowest: dc_init)
+        switch (t.format) {
+        case 1: dc_texture<0x422u, 3u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
+        case 2: dc_texture<0x4228u, 4u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
+        case 3: dc_texture<0x422611u, 6u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
+        case 4: dc_texture<0x611u, 3u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
+        case 5: dc_texture<0x611611u, 6u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
+        default: dc_texture<0x1u, 1u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
         }
     }
 }
