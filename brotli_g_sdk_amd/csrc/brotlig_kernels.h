@@ -2066,7 +2066,9 @@ __device__ inline void duo_producer(DuoLds& D, const DecodeArgs& a)
                 DuoStep& S = acquire(k);
                 if (g == 0u && lane < 32u) {
                     S.ins[sl] = ok_cmd ? ins : 0u; S.tot[sl] = ok_cmd ? tot : 0u; S.rel0[sl] = rel0; S.lit_a[sl] = lit_a;
-                    S.dist[sl] = dist | (ok_cmd ? kDuoOk : 0u) | (cp ? kDuoCopies : 0u);
+                    // (the distance only where the copy is valid: a damaged stream's ring code can wrap below zero -- 1 - 3 -- and its high bits
+                    // would read as the flags; a copy that is not valid is not made, as in decode_pages)
+                    S.dist[sl] = (cp ? dist : 0u) | (ok_cmd ? kDuoOk : 0u) | (cp ? kDuoCopies : 0u);
                 }
                 if (lane == 0u) { S.kind = kDuoGroup | (g == 0u ? kDuoRound : 0u); S.round_bytes = round_bytes; S.litcount = litcount; S.f0 = F0; }
                 uint8_t* const lits = reinterpret_cast<uint8_t*>(S.lits);

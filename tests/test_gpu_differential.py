@@ -128,6 +128,31 @@ def test_truncated_and_damaged_single_assets(api):
     assert np.array_equal(out, good_d)
 
 
+def test_damaged_distance_below_zero_in_either_kernel(api):
+    """Five damaged streams from the device soak of round 4 (a ring code applied to a small distance wraps below zero): the two-wavefront
+    kernel handed the wrapped distance to its consumer with the flags OR-ed on top -- a memory access fault on the device.  Both kernels
+    must refuse the copy and report a bad page; a valid stream in the same launch stays bit-exact."""
+    good_d, good_s = _valid_reference(api)
+    streams, sizes = [], []
+    for seed in (150069, 150248, 150466, 151219, 151529):
+        d, kw = random_plain(seed)
+        bad, kind = corrupt(E.encode(d, **kw), seed)
+        streams.append(bad); sizes.append(len(d))
+    streams.append(good_s); sizes.append(len(good_d))
+    for mode in (0, 1, 2):
+        api.DebugSetDecodeMode(mode)
+        try:
+            dec = api.BatchDecoder(streams, out_sizes=sizes)
+            dec.poison_output()
+            with pytest.raises(api.BrotligError):
+                dec.decode()
+            assert np.array_equal(dec.output(len(streams) - 1), good_d), mode
+        finally:
+            api.DebugSetDecodeMode(0)
+    out, _ = api.DecodeGPU(good_s)
+    assert np.array_equal(out, good_d)
+
+
 def test_undersized_output_buffer_is_refused_for_preconditioned_streams(api):
     """the de-conditioning kernel writes the whole texture; with out_bytes smaller than the texture the
     stream must be rejected by the prepare kernel (status), and nothing may be written past out_bytes."""

@@ -62,3 +62,16 @@ def test_sim_duo_rounds_of_many_groups(sim):
     assert rc == 0 and np.array_equal(ref, data)
     outs, status = run_batch(sim, [stream], [len(data)], grid=2)
     assert status == 0 and np.array_equal(outs[0], ref)
+
+
+@pytest.mark.parametrize("seed", [150069, 150248, 150466, 151219, 151529])
+def test_sim_duo_damaged_distance_below_zero_is_not_copied(sim, seed):
+    """Damaged streams from the device soak (profiles/tools/soak.py, seeds 150000..): a ring code applied to a small distance wraps below
+    zero (1 - 3).  decode_pages refuses the copy (distance > position); the producer used to hand the raw distance to the consumer with
+    its flags OR-ed on top, the wrapped value's high bits read as "valid copy", and the consumer fetched from far outside the buffers (a
+    memory access fault on the device, a segmentation fault here).  The page must end with the bad-page status and nothing else."""
+    from fuzzcases import corrupt, random_plain
+    d, kw = random_plain(seed)
+    bad, kind = corrupt(E.encode(d, **kw), seed)
+    outs, status = run_batch(sim, [bad], [len(d)], grid=2)
+    assert status & 2, (seed, kind, status)
