@@ -304,7 +304,9 @@ def main():
         import glob
         for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
             t = json.load(open(tpath))
-            if t.get("kernel_source_sha16") == ksha:
+            # (`also_valid_for`: later states of the source whose decode loop is the measured one instruction for instruction -- each listed
+            # with its reason in the file)
+            if t.get("kernel_source_sha16") == ksha or ksha in t.get("also_valid_for", {}):
                 # calibrated on known byte counts (profiles/r03_traffic_calibration.md): every L2 read request beyond L2 is a
                 # 128-byte line that FETCH_SIZE tallies as 64, WRITE_SIZE is right as it stands
                 traffic = int(t.get("traffic_bytes_per_launch_calibrated", t["traffic_bytes_per_launch_fetch_doubled"]))

@@ -892,7 +892,9 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
         job.page_off = i * si.page_size;
         job.dc = si.preconditioned ? a.dc + lo : nullptr;
         job.out = dst_base + abs_out;
-        if (abs_out + job.out_size > stream_out_end(streams[lo], out_bytes) || job.in_size > room || dst_base == nullptr) {
+        // (an empty page is not a page: with a damaged table entry it can lie anywhere -- `room` is 0 beyond the stream and 0 > 0 let it through,
+        // the bit readers then started at an address outside the input; found by the device soak of round 4)
+        if (abs_out + job.out_size > stream_out_end(streams[lo], out_bytes) || job.in_size > room || job.in_size == 0u || dst_base == nullptr) {
             job.valid = false;
             atomicOr(a.status, kStatusBadPage);
         }

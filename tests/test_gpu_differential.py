@@ -153,6 +153,34 @@ def test_damaged_distance_below_zero_in_either_kernel(api):
     assert np.array_equal(out, good_d)
 
 
+def test_empty_page_behind_a_damaged_table_entry_is_rejected(api):
+    """Batch 150080 of round 4's device soak (forty damaged streams, output sizes as their headers claim, a valid stream last): one of
+    them describes a page of zero bytes outside its stream, which fetch_job let through -- a memory access fault in either kernel.  Any
+    status, no fault, the valid neighbour bit-exact, in all three kernel modes."""
+    streams, good = [], None
+    for seed in range(150080, 150120):
+        d, kw = random_plain(seed)
+        bad, kind = corrupt(E.encode(d, **kw), seed)
+        streams.append(bad)
+    good, kw = random_plain(3)
+    streams.append(E.encode(good, **kw))
+    for mode in (0, 1, 2):
+        api.DebugSetDecodeMode(mode)
+        try:
+            try:
+                dec = api.BatchDecoder(streams, out_sizes=None)
+            except api.BrotligError:
+                continue
+            dec.poison_output()
+            try:
+                dec.decode()
+            except api.BrotligError:
+                pass
+            assert np.array_equal(dec.output(len(streams) - 1), good), mode
+        finally:
+            api.DebugSetDecodeMode(0)
+
+
 def test_undersized_output_buffer_is_refused_for_preconditioned_streams(api):
     """the de-conditioning kernel writes the whole texture; with out_bytes smaller than the texture the
     stream must be rejected by the prepare kernel (status), and nothing may be written past out_bytes."""

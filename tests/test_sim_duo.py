@@ -75,3 +75,34 @@ def test_sim_duo_damaged_distance_below_zero_is_not_copied(sim, seed):
     bad, kind = corrupt(E.encode(d, **kw), seed)
     outs, status = run_batch(sim, [bad], [len(d)], grid=2)
     assert status & 2, (seed, kind, status)
+
+
+def _damaged_batch_150080():
+    """Batch 150080 of the device soak: forty damaged streams and a valid one, output sizes as the damaged headers claim them."""
+    from brotli_g_sdk_amd.api import DecompressedSize
+    from fuzzcases import corrupt, random_plain
+    streams, sizes = [], []
+    for seed in range(150080, 150120):
+        d, kw = random_plain(seed)
+        bad, kind = corrupt(E.encode(d, **kw), seed)
+        try:
+            n = int(DecompressedSize(bad))
+        except Exception:
+            n = len(d)
+        streams.append(bad); sizes.append(n if n <= (64 << 20) else len(d))
+    good, kw = random_plain(3)
+    streams.append(E.encode(good, **kw)); sizes.append(len(good))
+    return streams, sizes, good
+
+
+def test_sim_empty_page_behind_a_damaged_table_entry_is_rejected(sim):
+    """A damaged page table can describe a page of zero bytes anywhere: beyond its stream the room is 0, and "0 > 0" let it through
+    fetch_job -- the bit readers then started at an address outside the input (a memory access fault on the device in round 4's soak, in
+    either kernel; a segmentation fault here).  An empty page is rejected now; the valid stream next to it stays bit-exact."""
+    streams, sizes, good = _damaged_batch_150080()
+    outs, status = run_batch(sim, streams, sizes, grid=300)
+    assert status != 0 and np.array_equal(outs[-1], good)
+    sim.sim_set_duo(0)                                              # and through the one-wavefront kernel
+    outs, status = run_batch(sim, streams, sizes, grid=300)
+    sim.sim_set_duo(1)
+    assert status != 0 and np.array_equal(outs[-1], good)
