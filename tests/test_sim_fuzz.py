@@ -89,3 +89,30 @@ def test_sim_damaged_header_cannot_reach_a_neighbouring_stream(sim):
     outs, status = run_batch(sim, [bad, E.encode(good, **kw)], [len(d), len(good)])
     assert status != 0
     assert np.array_equal(outs[1], good)
+
+
+@pytest.mark.parametrize("duo", [0, 1], ids=["one_wavefront", "two_wavefronts"])
+@pytest.mark.parametrize("base", range(150000, 150320, 40))
+def test_sim_damaged_batches_sized_by_their_own_headers(sim, base, duo):
+    """What the device soak does (profiles/tools/soak.py): forty damaged streams and a valid one in ONE launch, every output region sized by
+    what the damaged header claims.  Round 4's soak found two memory access faults this way that single streams with the true sizes never
+    showed (an empty page outside its stream; a wrapped distance in the two-wavefront kernel).  Both kernels; any status, no fault (the
+    simulator turns an out-of-bounds access into a crash), the valid neighbour bit-exact."""
+    from brotli_g_sdk_amd.api import DecompressedSize
+    streams, sizes = [], []
+    for seed in range(base, base + 40):
+        d, kw = random_plain(seed)
+        bad, kind = corrupt(E.encode(d, **kw), seed)
+        try:
+            n = int(DecompressedSize(bad))
+        except Exception:
+            n = len(d)
+        streams.append(bad); sizes.append(n if 0 < n <= (16 << 20) else len(d))
+    good, kw = random_plain(3)
+    streams.append(E.encode(good, **kw)); sizes.append(len(good))
+    sim.sim_set_duo(duo)
+    try:
+        outs, status = run_batch(sim, streams, sizes, grid=64)
+    finally:
+        sim.sim_set_duo(0)
+    assert np.array_equal(outs[-1], good)
