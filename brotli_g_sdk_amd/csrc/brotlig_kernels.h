@@ -351,7 +351,7 @@ __device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a <
 __device__ __forceinline__ uint32_t bit_width_u32(uint32_t x) { return x ? 32u - (uint32_t)__clz((int)x) : 0u; }
 __device__ __forceinline__ uint32_t ctz_u32(uint32_t x) { return (uint32_t)__ffs((int)x) - 1u; }      // x != 0
 __device__ __forceinline__ uint32_t msb_u32(uint32_t x) { return 31u - (uint32_t)__clz((int)x); }     // x != 0
-__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }     // (any byte address: a damaged page table can place a page anywhere)
 
 // Unaligned 8-byte access (gfx950 global memory takes any byte address; hipcc emits dwordx2).
 __device__ __forceinline__ uint64_t load_u64u(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
