@@ -297,7 +297,8 @@ def main():
 
     # HBM traffic cannot be counted from inside this process (it needs rocprofv3 --pmc passes).  The committed
     # measurement of the same command is attached only when it was taken on THIS kernel source (the file
-    # records a hash of csrc/brotlig_kernels.h); a measurement of another build is dropped, not reused.
+    # records a hash of csrc/brotlig_kernels.h, and the later source states it names as the same decode loop, each with its reason); a
+    # measurement of another build is dropped, not reused.
     traffic, traffic_src = None, None
     ksha = kernel_source_hash()
     if args.workload == "mixed" and args.streams == 16 and args.pages_per_stream == 4096 and distinct == 256 and not args.preencoded and not args.encoder_flags:
@@ -310,8 +311,10 @@ def main():
                 # calibrated on known byte counts (profiles/r03_traffic_calibration.md): every L2 read request beyond L2 is a
                 # 128-byte line that FETCH_SIZE tallies as 64, WRITE_SIZE is right as it stands
                 traffic = int(t.get("traffic_bytes_per_launch_calibrated", t["traffic_bytes_per_launch_fetch_doubled"]))
+                measured = t.get("kernel_source_sha16")
                 traffic_src = (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE, separate passes; "
-                               f"2 x FETCH_SIZE + WRITE_SIZE as calibrated in profiles/r03_traffic_calibration.md; kernel source {ksha})")
+                               f"2 x FETCH_SIZE + WRITE_SIZE as calibrated in profiles/r03_traffic_calibration.md; kernel source {measured}"
+                               + ("" if measured == ksha else f", which the file lists as the decode loop of this source {ksha} too: {t['also_valid_for'][ksha]}") + ")")
                 break
 
     # Roofline of the step's dominant kernel(s).  Plain streams: (C + U) over the decode kernel.  Pre-conditioned
