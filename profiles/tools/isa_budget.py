@@ -149,6 +149,29 @@ def stage_of(stack, marks, fn_line):
     return "0 wave setup"
 
 
+def round_loop_scratch(co, kernel="brotlig_decode_kernel"):
+    """Scratch accesses inside the round loops of a code object: [(loop start, loop end, instructions, [(address, opcode), ...]), ...].
+    A round loop is a natural loop (back edge) that contains the s_setprio around the copy levels -- only a round has one -- and no
+    global atomic (the page loop around it takes pages from the work counter): both instantiations' round and group loops, whatever their size.  tests/test_kernel_isa.py asserts on this."""
+    sym, start, _ = kernel_symbol(co, kernel)
+    insts = disassemble(co, sym)
+    loops = set()
+    for i in insts:
+        if i["op"].startswith(("s_cbranch", "s_branch")) and i["label"] is not None and start + i["label"] <= i["addr"]:
+            loops.add((start + i["label"], i["addr"]))
+    prio = [i["addr"] for i in insts if i["op"] == "s_setprio"]
+    out = []
+    for lo, hi in sorted(loops):
+        if not any(lo <= p <= hi for p in prio):
+            continue
+        body = [i for i in insts if lo <= i["addr"] <= hi]
+        if any(i["op"].startswith(("global_atomic", "flat_atomic")) for i in body):
+            continue        # the page loop around the rounds (it takes pages from the work counter); a few reloads per PAGE are tolerated
+        sc = [(hex(i["addr"] - start), i["op"]) for i in body if i["op"].startswith("scratch_")]
+        out.append((hex(lo - start), hex(hi - start), len(body), sc))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kernel", default="brotlig_decode_kernel")
@@ -211,18 +234,7 @@ def main():
     # Scratch accesses inside the round loops, from the build WITHOUT -g (the one that ships): -g moves the register allocation, and
     # a spill inside a round (one scratch round trip per round: 4-5 % of the kernel when it happened in round 4) does not show in the
     # -g listing.  Round loops = natural loops of 1 500 .. 4 000 instructions (one per instantiation of the page loop).
-    insts_n = disassemble(co_n, kernel_symbol(co_n, a.kernel)[0])
-    start_n = kernel_symbol(co_n, a.kernel)[1]
-    round_loops = set()
-    for i in insts_n:
-        if i["op"].startswith(("s_cbranch", "s_branch")) and i["label"] is not None and start_n + i["label"] <= i["addr"]:
-            round_loops.add((start_n + i["label"], i["addr"]))
-    spills_in_rounds = []
-    for lo, hi in sorted(round_loops):
-        n = sum(1 for i in insts_n if lo <= i["addr"] <= hi)
-        if 1500 <= n <= 4000:
-            sc = [(hex(i["addr"] - start_n), i["op"]) for i in insts_n if lo <= i["addr"] <= hi and i["op"].startswith("scratch_")]
-            spills_in_rounds.append((hex(lo - start_n), hex(hi - start_n), n, sc))
+    spills_in_rounds = round_loop_scratch(co_n, a.kernel)
     classes = ["VALU", "SALU", "BRANCH", "WAIT", "LDS", "VMEM", "SCRATCH", "SMEM", "OTHER"]
     print(f"kernel {sym}: {len(insts)} instructions, {size} bytes (-g) / {size_n} bytes (no -g){'' if same else '  ** SIZES DIFFER: -g changed the code **'}")
     print(f"{'stage':36s} " + " ".join(f"{c:>7s}" for c in classes) + "   total")
@@ -233,7 +245,7 @@ def main():
         print(f"{s:36s} " + " ".join(f"{c[k]:7d}" for k in classes) + f"  {sum(c.values()):6d}")
         tot.update(c)
     print(f"{'TOTAL':36s} " + " ".join(f"{tot[k]:7d}" for k in classes) + f"  {sum(tot.values()):6d}")
-    print("\nscratch accesses inside round-sized loops of the build without -g (must be none):")
+    print("\nscratch accesses inside the round loops (the loops around the copy levels' s_setprio) of the build without -g (must be none):")
     seen = set()
     for lo, hi, n, sc in spills_in_rounds:
         if not any(abs(int(lo, 16) - int(l2, 16)) < 64 for l2 in seen) or sc:
