@@ -23,3 +23,14 @@ def test_no_scratch_access_inside_a_round():
     assert len(outer) >= 2, loops                           # the two-page and the one-page instantiation of the page loop, at least
     spilled = [(lo, hi, n, sc) for lo, hi, n, sc in loops if sc]
     assert not spilled, "scratch access inside a round: %r" % spilled
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles gfx950 without a GPU)")
+def test_small_batch_and_deconditioning_kernels_do_not_spill():
+    """The two-wavefront kernel (256 registers to spend) and the de-conditioning gather keep everything in registers."""
+    import isa_budget
+    co = isa_budget.build([], False)
+    for name in ("brotlig_decode_duo_kernel", "brotlig_decondition_kernel"):
+        sym, start, size = isa_budget.kernel_symbol(co, name)
+        scratch = [i["op"] for i in isa_budget.disassemble(co, sym) if i["op"].startswith("scratch_")]
+        assert not scratch, (name, scratch[:8])
