@@ -42,7 +42,7 @@ def build_cpu(force=False):
 
 
 def hip_sources():
-    names = ["brotlig_hip.hip", "brotlig_streamer.hip", "brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h", "brotlig_shard_plan.h"]
+    names = ["brotlig_hip.hip", "brotlig_streamer.hip", "brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h", "brotlig_shard_plan.h", "brotlig_internal.h"]
     return [os.path.join(CSRC, n) for n in names] + [os.path.join(ROOT, "include", "brotlig_amd.h")]
 
 

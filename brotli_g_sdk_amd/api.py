@@ -6,6 +6,7 @@ entry the benchmark times.  There is no CPU decode path here: if libbrotlig_hip.
 no HIP device is usable, the calls raise.  torch is used only to own device memory and streams.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -97,6 +98,16 @@ def lib():
         L.BrotligDecodeBatchDevice.argtypes = batch
         L.BrotligDecodeBatchStatus.restype = ctypes.c_int
         L.BrotligDecodeBatchStatus.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        try:
+            L.BrotligDecodeBatchStreamStatus.restype = ctypes.c_int
+            L.BrotligDecodeBatchStreamStatus.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+            L.BrotligStreamerStreamResult.restype = ctypes.c_int
+            L.BrotligStreamerStreamResult.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32]
+            L.BrotligDebugKnobsEnabled.restype = ctypes.c_uint32
+        except AttributeError:
+            # only an A/B build of an OLDER source loaded through BROTLIG_HIP_SO (profiles/tools/ab_run.py) may lack the round-5 entries
+            if not os.environ.get("BROTLIG_HIP_SO"):
+                raise
         L.BrotligDecodeBatchTimed.restype = ctypes.c_int
         L.BrotligDecodeBatchTimed.argtypes = batch + [ctypes.c_uint32, ctypes.c_uint32,
                                                       ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
@@ -225,6 +236,10 @@ class MultiDeviceAsync:
         self.keep = (decoders, streams)
         rc = lib().BrotligDecodeBatchMultiDeviceAsync(ctypes.addressof(self.arr), self.n, ctypes.sizeof(DeviceBatch))
         if rc != BROTLIG_OK:
+            # the C side has enqueued every shard it could (it records a result per shard and goes on): their kernels are writing the
+            # decoders' buffers, so they are waited for before the half-built object is dropped -- Wait only touches the
+            # shards whose enqueue succeeded
+            lib().BrotligDecodeBatchMultiDeviceWait(ctypes.addressof(self.arr), self.n, ctypes.sizeof(DeviceBatch))
             raise BrotligError(rc, "BrotligDecodeBatchMultiDeviceAsync")
 
     def wait(self):
@@ -235,9 +250,23 @@ class MultiDeviceAsync:
         return results
 
 
+def _debug_knobs(L):
+    """The two diagnostics switches are inert unless the process has BROTLIG_ENABLE_DEBUG_KNOBS=1 in its environment when the library
+    first launches (the library reads it once); tests/conftest.py sets it.  Asking for a knob in a process without it is an error here
+    rather than a silent no-op."""
+    if os.environ.get("BROTLIG_ENABLE_DEBUG_KNOBS") != "1" or not L.BrotligDebugKnobsEnabled():
+        raise RuntimeError("BrotligDebugSet* are inert: start the process with BROTLIG_ENABLE_DEBUG_KNOBS=1 (diagnostics only)")
+
+
+def DebugKnobsEnabled():
+    return bool(lib().BrotligDebugKnobsEnabled())
+
+
 def DebugSetDecodeGrid(workgroups):
     """BrotligDebugSetDecodeGrid (diagnostics): 0 = the normal launch rule."""
     L = lib()
+    if workgroups:
+        _debug_knobs(L)
     L.BrotligDebugSetDecodeGrid.restype = None
     L.BrotligDebugSetDecodeGrid.argtypes = [ctypes.c_uint32]
     L.BrotligDebugSetDecodeGrid(int(workgroups))
@@ -246,6 +275,8 @@ def DebugSetDecodeGrid(workgroups):
 def DebugSetDecodeMode(mode):
     """BrotligDebugSetDecodeMode (diagnostics): 0 = the normal rule, 1 = never two wavefronts per page, 2 = always."""
     L = lib()
+    if mode:
+        _debug_knobs(L)
     L.BrotligDebugSetDecodeMode.restype = None
     L.BrotligDebugSetDecodeMode.argtypes = [ctypes.c_uint32]
     L.BrotligDebugSetDecodeMode(int(mode))
@@ -335,6 +366,13 @@ class BatchDecoder:
                 raise BrotligError(rc, "BrotligDecodeBatchStatus")
             return total.value, kern.value
 
+    def stream_status(self):
+        """BrotligDecodeBatchStreamStatus: (batch result, [BROTLIG_ERROR per stream]) of the last decode -- which assets were damaged."""
+        with self.torch.cuda.device(self.device):
+            res = np.zeros(self.n, dtype=np.int32)
+            rc = lib().BrotligDecodeBatchStreamStatus(self.d_ws.data_ptr(), self.n, res.ctypes.data, self._stream())
+            return int(rc), [int(x) for x in res]
+
     PHASES = ("setup", "tables", "commands", "ring", "positions", "literals", "group_setup", "level_tail",
               "delta", "total", "rounds", "levels", "lv_short", "lv_bytes", "lv_long_and_far", "solo_rounds",
               "cmd_symbol", "cmd_extra_bits", "slide", "pieces_and_far_loads", "bitmaps", "groups", "lit_steps", "lv_overlap", "team_levels",
@@ -349,6 +387,17 @@ class BatchDecoder:
             if rc != BROTLIG_OK:
                 raise BrotligError(rc, "BrotligDecodePhaseProfile")
             return dict(zip(self.PHASES, (int(x) for x in out)))
+
+    def wave_times(self):
+        """(first, last) tick of a 100 MHz counter for every wavefront of one launch of the phase-timer twin (diagnostics: the tail)."""
+        with self.torch.cuda.device(self.device):
+            self.torch.cuda.synchronize()
+            grid = int(lib().BrotligKernelGridSize())
+            out = np.zeros(len(self.PHASES) + 2 * grid, dtype=np.uint64)
+            rc = lib().BrotligDecodePhaseProfile(*self._args(None)[:9], out.ctypes.data, len(out))
+            if rc != BROTLIG_OK:
+                raise BrotligError(rc, "BrotligDecodePhaseProfile")
+            return out[len(self.PHASES):].reshape(grid, 2)
 
     def output(self, i):
         """Decompressed bytes of stream i as a host uint8 array."""
@@ -415,6 +464,18 @@ class Streamer:
             self._keep.pop(ticket, None)            # nothing left to fetch for this ticket
         if rc != BROTLIG_OK:
             raise BrotligError(rc, "BrotligStreamerWait")
+
+    def stream_results(self, ticket, n):
+        """BrotligStreamerStreamResult for streams 0..n-1 of the batch: BROTLIG_ERROR per stream (waits for the batch)."""
+        return [int(lib().BrotligStreamerStreamResult(self._h, ticket, i)) for i in range(n)]
+
+    def output(self, ticket, index):
+        """BrotligStreamerOutput: the decoded bytes of one stream (a copy), or None for a damaged stream / an unknown ticket."""
+        sz = ctypes.c_uint32()
+        p = lib().BrotligStreamerOutput(self._h, ticket, index, ctypes.byref(sz))
+        if not p:
+            return None
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(sz.value,)).copy()
 
     def result(self, ticket):
         """Waits for the batch and returns its decoded streams as fresh arrays."""

@@ -6,6 +6,7 @@
 // device-pointer batch call.  No decoding happens on the host.
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
@@ -21,8 +22,9 @@
 #include "brotlig_amd.h"
 #include "brotlig_kernels.h"
 #include "brotlig_shard_plan.h"
-#ifdef BROTLIG_WITH_SPLIT     // experiment builds only (profiles/experiments/r03_split_path.md): not part of the product library
-#include "experimental/brotlig_split_kernels.h"
+#include "brotlig_internal.h"
+#ifdef BROTLIG_WITH_SPLIT     // experiment builds only (profiles/experiments/r03_split_path.md, built with -I profiles/experiments/split_path): not part of the product
+#include "brotlig_split_kernels.h"
 #endif
 
 using namespace brotlig;
@@ -49,7 +51,7 @@ constexpr uint32_t kMaxDecodeGrid = 8192;
 constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
 size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
 size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
-// Split path (experimental/brotlig_split_kernels.h): an A/B experiment of round 3, compiled in with -DBROTLIG_WITH_SPLIT only and then
+// Split path (profiles/experiments/split_path/brotlig_split_kernels.h): an A/B experiment of round 3, compiled in with -DBROTLIG_WITH_SPLIT only and then
 // switched on with BROTLIG_SPLIT=1|2.  Per page one slot of (cap + 1) command words and a literal array of a page plus
 // slack, and two header words.
 #ifdef BROTLIG_WITH_SPLIT
@@ -82,9 +84,18 @@ int diag_wg_per_cu() { static const int v = env_int_once("BROTLIG_WG_PER_CU"); r
 int diag_policy() { static const int v = env_int_once("BROTLIG_POLICY"); return v; }
 // Diagnostics (tests): a fixed decode grid, so that a SMALL batch can be decoded two pages per wavefront (grid < pages / 2) as well as
 // one page per wavefront (the default for it).  0 = the normal rule.  Process-wide, not thread-safe: tests only.
-std::atomic<uint32_t> g_debug_grid{0};
+// Round 5: both knobs are INERT unless the process was started with BROTLIG_ENABLE_DEBUG_KNOBS=1 (read once, like the other
+// diagnostics switches): in a production process no thread and no forgotten reset can change which kernel a launch uses.
+bool diag_knobs_enabled() { static const bool v = env_int_once("BROTLIG_ENABLE_DEBUG_KNOBS") == 1; return v; }
+std::atomic<uint32_t> g_debug_grid_value{0}, g_debug_mode_value{0};
+struct DebugKnob {
+    std::atomic<uint32_t>& v;
+    uint32_t load() const { return diag_knobs_enabled() ? v.load() : 0u; }
+    void store(uint32_t x) { v.store(x); }
+};
+DebugKnob g_debug_grid{g_debug_grid_value};
 // Diagnostics (tests, profiles/tools/latency.py): 0 = the normal rule, 1 = never the two-wavefronts-per-page kernel, 2 = always.
-std::atomic<uint32_t> g_debug_mode{0};
+DebugKnob g_debug_mode{g_debug_mode_value};
 // Batches that cannot hold more pages than this (every page >= 32 KiB of the caller's output region) are decoded two wavefronts per
 // page (brotlig_decode_duo_kernel): the machine has four SIMDs per compute unit and a page alone keeps one of them busy.
 constexpr uint64_t kDuoMaxPages = BROTLIG_DUO_MAX_PAGES;
@@ -115,7 +126,7 @@ BROTLIG_ERROR grid_sizes(Grids* out)
         if (granules > 0 && per_cu > 128 / granules) per_cu = 128 / granules;
         if (diag_wg_per_cu() > 0) per_cu = diag_wg_per_cu();
         if (per_cu < 1) per_cu = 1;
-        g.decond = cus * 8;
+        g.decond = cus * (env_int_once("BROTLIG_DC_PER_CU") > 0 ? env_int_once("BROTLIG_DC_PER_CU") : 32);   // wavefronts of the de-conditioning kernel (one per workgroup, 4 KiB of LDS each): 8 per SIMD
         g.duo = cus * kDuoPerCu;
         g.order = cus * 4;
         g.decode = cus * per_cu < (int)kMaxDecodeGrid ? cus * per_cu : (int)kMaxDecodeGrid;
@@ -250,10 +261,10 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     }
     if (k1) HIP_OK(hipEventRecord(k1, s));
     if (a.scratch != nullptr) {   // (without a scratch buffer no stream of the batch can be pre-conditioned: the prepare kernel rejects them)
-        // streams over y, each stream's tiles over x; about 8 workgroups of 256 per CU in total
+        // streams over y, each stream's super-tiles over the wavefronts of x; 32 wavefronts per CU in total
         const unsigned gy = a.num_streams < 32u ? a.num_streams : 32u;
         const unsigned gx = ((unsigned)g.decond + gy - 1u) / gy;
-        hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(gx, gy), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(gx, gy), dim3(64), 0, s, a);
     }
     HIP_OK(hipGetLastError());
     return BROTLIG_OK;
@@ -307,6 +318,26 @@ extern "C" BROTLIG_ERROR BrotligDecodeBatchStatus(const void* d_workspace, void*
     HIP_OK(hipMemcpyAsync(&st, d_workspace, sizeof st, hipMemcpyDeviceToHost, static_cast<hipStream_t>(hip_stream)));
     HIP_OK(hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)));
     return status_to_error(st);
+}
+
+// The stream's own status word lives in its DcTable record of the workspace (every stream has one); one strided copy brings all of them back.
+hipError_t brotlig::enqueue_stream_status_copy(const void* d_workspace, uint32_t num_streams, uint32_t* h_words, hipStream_t stream)
+{
+    const uint8_t* first = static_cast<const uint8_t*>(d_workspace) + dc_offset(num_streams) + offsetof(DcTable, status);
+    return hipMemcpy2DAsync(h_words, sizeof(uint32_t), first, sizeof(DcTable), sizeof(uint32_t), num_streams, hipMemcpyDeviceToHost, stream);
+}
+
+extern "C" BROTLIG_ERROR BrotligDecodeBatchStreamStatus(const void* d_workspace, uint32_t num_streams, int32_t* results, void* hip_stream)
+{
+    if (!d_workspace || !results || num_streams == 0) return BROTLIG_ERROR_GENERIC;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    std::vector<uint32_t> words;
+    try { words.resize(num_streams); } catch (...) { return BROTLIG_ERROR_GENERIC; }
+    HIP_OK(enqueue_stream_status_copy(d_workspace, num_streams, words.data(), s));
+    HIP_OK(hipStreamSynchronize(s));
+    uint32_t all = 0;
+    for (uint32_t i = 0; i < num_streams; ++i) { results[i] = (int32_t)status_to_error(words[i]); all |= words[i]; }
+    return status_to_error(all);
 }
 
 extern "C" BROTLIG_ERROR BrotligDecodeBatchTimed(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
@@ -390,10 +421,16 @@ BROTLIG_ERROR decode_gpu(BrotligContext& c, uint32_t input_size, const uint8_t* 
     if (si.preconditioned) if (BROTLIG_ERROR e = grow(c.scratch, c.scratch_cap, out_alloc + 64)) return e;
     if (BROTLIG_ERROR e = grow(c.ws, c.ws_cap, ws_size)) return e;
     if (!c.desc.p) HIP_OK(hipMalloc(&c.desc.p, sizeof(BrotligStreamDesc)));
-    *c.h_desc = BrotligStreamDesc{0, 0, input_size, *output_size};      // pinned and owned by the context: no wait before the launches
     HIP_OK(hipMemsetAsync(static_cast<uint8_t*>(c.in.p) + (in_alloc + 64 - 80), 0, 80, c.stream));
     HIP_OK(hipMemcpyAsync(c.in.p, input, input_size, hipMemcpyHostToDevice, c.stream));
-    HIP_OK(hipMemcpyAsync(c.desc.p, c.h_desc, sizeof(BrotligStreamDesc), hipMemcpyHostToDevice, c.stream));
+    const BrotligStreamDesc desc{0, 0, input_size, *output_size};
+    if (c.h_desc) {     // a kept context: pinned and owned by it, no wait between the upload and the launches
+        *c.h_desc = desc;
+        HIP_OK(hipMemcpyAsync(c.desc.p, c.h_desc, sizeof desc, hipMemcpyHostToDevice, c.stream));
+    } else {            // the stateless entry: from the stack, the copy is complete when the call returns (no pinned allocation per call)
+        HIP_OK(hipMemcpyAsync(c.desc.p, &desc, sizeof desc, hipMemcpyHostToDevice, c.stream));
+        HIP_OK(hipStreamSynchronize(c.stream));
+    }
     const DecodeArgs a = make_args(c.in.p, input_size, c.out.p, out_alloc, static_cast<BrotligStreamDesc*>(c.desc.p), 1,
                                    c.ws.p, ws_size, si.preconditioned ? c.scratch.p : nullptr);
     BROTLIG_ERROR err = enqueue(a, c.stream, c.e0.e, c.e1.e);
@@ -408,13 +445,13 @@ BROTLIG_ERROR decode_gpu(BrotligContext& c, uint32_t input_size, const uint8_t* 
     return BROTLIG_OK;
 }
 
-BROTLIG_ERROR context_init(BrotligContext& c, int device)
+BROTLIG_ERROR context_init(BrotligContext& c, int device, bool kept)
 {
     if (device < 0) HIP_OK(hipGetDevice(&device)); else HIP_OK(hipSetDevice(device));
     c.device = device;
     HIP_OK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     HIP_OK(c.e0.create()); HIP_OK(c.e1.create());
-    HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c.h_desc), sizeof(BrotligStreamDesc), hipHostMallocDefault));
+    if (kept) HIP_OK(hipHostMalloc(reinterpret_cast<void**>(&c.h_desc), sizeof(BrotligStreamDesc), hipHostMallocDefault));
     return BROTLIG_OK;
 }
 
@@ -434,7 +471,7 @@ extern "C" BROTLIG_ERROR BrotligContextCreate(int device, BrotligContext** out)
     BrotligContext* c = new (std::nothrow) BrotligContext;
     if (!c) return BROTLIG_ERROR_GENERIC;
     DeviceGuard guard;
-    if (BROTLIG_ERROR e = context_init(*c, device)) { delete c; return e; }
+    if (BROTLIG_ERROR e = context_init(*c, device, true)) { delete c; return e; }
     *out = c;
     return BROTLIG_OK;
 }
@@ -461,7 +498,7 @@ extern "C" BROTLIG_ERROR DecodeGPU(int /*useWarpDevice*/, uint32_t input_size, c
                                    uint32_t* output_size, uint8_t* output, double* time_ms)
 {
     BrotligContext c;                                                   // (its destructor releases the stream on every path)
-    if (BROTLIG_ERROR e = context_init(c, -1)) return e;
+    if (BROTLIG_ERROR e = context_init(c, -1, false)) return e;
     return decode_gpu(c, input_size, input, output_size, output, time_ms);
 }
 
@@ -643,8 +680,9 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     Grids g;
     if (BROTLIG_ERROR e = grid_sizes(&g)) return e;
     DevBuf prof;
-    HIP_OK(hipMalloc(&prof.p, kNumPhases * sizeof(unsigned long long)));
-    HIP_OK(hipMemset(prof.p, 0, kNumPhases * sizeof(unsigned long long)));
+    const size_t prof_words = (size_t)kNumPhases + 2u * (size_t)g.decode;   // phase sums, then {first, last} 100 MHz tick of every wavefront
+    HIP_OK(hipMalloc(&prof.p, prof_words * sizeof(unsigned long long)));
+    HIP_OK(hipMemset(prof.p, 0, prof_words * sizeof(unsigned long long)));
     DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, ws_bytes, d_scratch);
     a.prof = static_cast<unsigned long long*>(prof.p);
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), nullptr));
@@ -656,14 +694,15 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, nullptr, a);
     hipLaunchKernelGGL(brotlig_decode_kernel_timed, dim3(g.decode), dim3(64), 0, nullptr, a);
     HIP_OK(hipDeviceSynchronize());
-    unsigned long long h[kNumPhases];
-    HIP_OK(hipMemcpy(h, prof.p, sizeof h, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n_out; ++i) cycles_out[i] = i < (uint32_t)kNumPhases ? h[i] : 0;
+    std::vector<unsigned long long> h(prof_words);
+    HIP_OK(hipMemcpy(h.data(), prof.p, prof_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_out; ++i) cycles_out[i] = i < prof_words ? h[i] : 0;
     return BROTLIG_OK;
 }
 
 extern "C" void BrotligDebugSetDecodeGrid(uint32_t workgroups) { g_debug_grid.store(workgroups); }
 extern "C" void BrotligDebugSetDecodeMode(uint32_t mode) { g_debug_mode.store(mode); }
+extern "C" uint32_t BrotligDebugKnobsEnabled(void) { return diag_knobs_enabled() ? 1u : 0u; }
 extern "C" uint32_t BrotligAbiVersion(void) { return BROTLIG_AMD_ABI_VERSION; }
 extern "C" uint32_t BrotligKernelLdsBytes(void) { return (uint32_t)sizeof(WaveLds); }
 extern "C" uint32_t BrotligKernelGridSize(void) { Grids g; return grid_sizes(&g) == BROTLIG_OK ? (uint32_t)g.decode : 0u; }

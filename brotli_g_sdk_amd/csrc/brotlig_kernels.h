@@ -61,9 +61,12 @@ struct DcTable {
     uint32_t sub_size[kMaxSubBlocks], sub_off[kMaxSubBlocks], sub_stream_off[kMaxSubBlocks + 1];
     uint32_t w[kMaxMips], h[kMaxMips], pitch[kMaxMips];
     uint32_t mip_off_bytes[kMaxMips + 1], mip_off_blocks[kMaxMips + 1];
-    uint32_t item_prefix[kMaxMips + 1];     // de-conditioning work items (2 x 32 tiles of row chunks, 64 each) before each mip
+    uint32_t item_prefix[kMaxMips + 1];     // de-conditioning work items before each mip: 64 per tile of 2 rows x 32 row chunks, every tile row
+                                            // padded to whole super-tiles of 4 tiles (brotlig_decondition_kernel): a multiple of 256
     uint32_t format;                        // 1..5 = BC1..BC5, 0 = unknown (one byte per block)
-    uint32_t pad[33];
+    uint32_t status;                        // kStatus* bits of THIS stream (every stream has a record, pre-conditioned or not): which asset of a
+                                            // batch was damaged (BrotligDecodeBatchStreamStatus); the batch-wide OR stays in DecodeArgs::status[0]
+    uint32_t pad[32];
 };
 static_assert(sizeof(DcTable) == 1024, "DcTable is addressed as 1 KiB records");
 
@@ -86,7 +89,7 @@ struct DecodeArgs {
                             // (canonical-code order) that do not fit the LDS arrays -- ranks kIcpSymCap.. and kDistSymCap..
     unsigned long long* prof;   // [kNumPhases] cycle sums, only written by the phase-timer instantiation
 #ifdef BROTLIG_WITH_SPLIT
-    // split path (experimental/brotlig_split_kernels.h): the entropy kernel leaves every compressed page as a command array and a
+    // split path (profiles/experiments/split_path/brotlig_split_kernels.h): the entropy kernel leaves every compressed page as a command array and a
     // literal array in global memory, the assembly kernel builds the page from them.  Slots are indexed by global page index.
     uint64_t* cmds;             // [pages][cmd_cap + 1] packed commands, then one terminal entry
     uint8_t*  lits;             // [pages][lit_stride] literals in consumption order
@@ -257,6 +260,7 @@ struct __attribute__((aligned(16))) PageLdsT {
     uint8_t  start_cum[G::kRoundMax / 32];  // per group: piece starts in earlier words of start_bits
     uint8_t  carry[64];             // ring of literals decoded ahead of their command (< 32 live)
     uint32_t page_params;           // NPOSTFIX | (NDIRECT << NPOSTFIX) << 8 | delta-coded flag << 16 of the page being decoded
+    uint32_t page_stream;           // index of its stream in the batch (read only when the page turns out damaged; lives in what was padding)
     uint32_t ring[8] __attribute__((aligned(16)));  // the distance ring, circular: the t-th distance pushed in the page lives in word t & 7 (DistanceRing)
     uint8_t  win[G::kWin + 16] __attribute__((aligned(16)));    // output window; doubles as the code-length
                                                                  // scratch (728 B) while tables are built
@@ -826,6 +830,7 @@ struct PageJob {
     uint32_t page_off;      // offset of the page in its stream's (conditioned) byte space
     const DcTable* dc;      // non-null for preconditioned streams
     uint32_t index;         // global page index (position in stream order, before the schedule)
+    uint32_t stream;        // index of the page's stream in the batch
     bool     valid;
 };
 
@@ -850,6 +855,14 @@ __device__ __forceinline__ uint32_t byte_add(uint32_t x, uint32_t c)
     return ((x & 0x7F7F7F7Fu) + (cc & 0x7F7F7F7Fu)) ^ ((x ^ cc) & 0x80808080u);
 }
 
+// A page of stream `s` failed: the batch-wide status word (the shader's meta[0], BrotliGCompute.hlsl:1757-1881) and the stream's own
+// (round 5: a batch of up to 4 096 assets names the damaged ones).  Rare path, one lane.
+__device__ __forceinline__ void flag_bad_page(const DecodeArgs& a, uint32_t s)
+{
+    atomicOr(a.status, kStatusBadPage);
+    atomicOr(&a.dc[s].status, kStatusBadPage);
+}
+
 // The job of global page index `g` (meaningful when `ok`): stream lookup, page table walk
 // (src/BrotligDecoder.cpp:310-314), bounds against the caller's buffers.
 __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, uint32_t g, bool ok)
@@ -857,7 +870,7 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
     PageJob job;
     job.valid = ok;
     job.in = nullptr; job.out = nullptr; job.in_size = job.out_size = 0; job.in_limit = 0; job.page_size = kMinPageSize;
-    job.page_off = 0; job.dc = nullptr; job.index = 0;
+    job.page_off = 0; job.dc = nullptr; job.index = 0; job.stream = 0;
     if (job.valid) {
         if (order != nullptr) g = order[g];                             // the schedule built by the order kernels
         job.index = g;
@@ -869,6 +882,7 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
         uint32_t lo = 0, hi = a.num_streams;
         while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (page_base[mid] <= g) lo = mid; else hi = mid; }
         const uint32_t i = g - page_base[lo];
+        job.stream = lo;
         const uint64_t s_in = streams[lo].in_offset, s_out = streams[lo].out_offset;
         const uint8_t* sp = in + s_in;
         StreamInfo si;
@@ -896,7 +910,7 @@ __device__ inline PageJob fetch_job(const DecodeArgs& a, const uint32_t* order, 
         // the bit readers then started at an address outside the input; found by the device soak of round 4)
         if (abs_out + job.out_size > stream_out_end(streams[lo], out_bytes) || job.in_size > room || job.in_size == 0u || dst_base == nullptr) {
             job.valid = false;
-            atomicOr(a.status, kStatusBadPage);
+            flag_bad_page(a, lo);
         }
     }
     return job;
@@ -1404,7 +1418,7 @@ __device__ __forceinline__ uint32_t piece_dependencies(uint32_t* start_bits, uin
 
 // ===========================================================================================
 // Stages of a page decode shared by the fused kernel (decode_pages) and the entropy kernel of the
-// split experiment (experimental/brotlig_split_kernels.h).  `Lds` is the per-half LDS record: both kinds carry
+// split experiment (profiles/experiments/split_path/brotlig_split_kernels.h).  `Lds` is the per-half LDS record: both kinds carry
 // lut_icp / lut_dist / lut_lit, sorted_*, limit, first_offs, page_params and ring_push under
 // these names; where a table's code lengths live while it is built differs (build_lens).
 // All of them run in wave-uniform control flow, with per-half predicates as operands.
@@ -1463,7 +1477,7 @@ __device__ __forceinline__ bool start_pages(const DecodeArgs& a, Lds& L, PageJob
             const uint32_t npostfix = (uint32_t)h & 3u;
             const uint32_t is_delta = ((((uint32_t)h >> 6) & 1u) != 0u && job.dc != nullptr) ? 1u : 0u;   // PageDecoder.cpp:87-88
             // kept in LDS rather than in a register for the whole page: read once per round at most
-            if (sl == 0u) L.page_params = npostfix | ((((uint32_t)h >> 2) & 15u) << (npostfix + 8u)) | (is_delta << 16);
+            if (sl == 0u) { L.page_params = npostfix | ((((uint32_t)h >> 2) & 15u) << (npostfix + 8u)) | (is_delta << 16); L.page_stream = job.stream; }
             const uint32_t base_bits = bit_width_u32((job.in_size + 31u) / 32u);
             const uint32_t dsize_bits = bit_width_u32(bit_width_u32(job.in_size - 1u));
             const uint32_t base_size = (uint32_t)(h >> 8) & ((1u << base_bits) - 1u);
@@ -1942,7 +1956,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
 
     // ---- per-page delta decode of the colour sub-streams
     delta_decode_page(job, ended && (L.page_params >> 16) != 0u && !bad, sl);
-    if (ended && bad && sl == 0u) atomicOr(a.status, kStatusBadPage);
+    if (ended && bad && sl == 0u) flag_bad_page(a, L.page_stream);
     }
     clk.lap(kPhDelta);
     clk.flush(a.prof, lane);
@@ -2122,7 +2136,7 @@ __device__ inline void duo_producer(DuoLds& D, const DecodeArgs& a)
             if (lane == 0u) S.kind = kDuoPageEnd | (verdict != 0ull ? kDuoBad : 0u) | ((L.page_params >> 16) != 0u ? kDuoDelta : 0u);
             publish(++k);
         }
-        if (ended && bad && sl == 0u) atomicOr(a.status, kStatusBadPage);
+        if (ended && bad && sl == 0u) flag_bad_page(a, L.page_stream);
     }
     DuoStep& S = acquire(k);
     if (lane == 0u) S.kind = kDuoFinish;
@@ -2290,7 +2304,7 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
         if ((uint64_t)t.pitch[m] < (uint64_t)t.w[m] * bb) fits = false;
         total += (uint64_t)t.w[m] * t.h[m];
         bytes += (uint64_t)t.pitch[m] * t.h[m];
-        items += (uint64_t)((t.h[m] + 1u) / 2u) * (((t.pitch[m] + bb - 1u) / bb + 31u) / 32u) * 64u;
+        items += (uint64_t)((t.h[m] + 1u) / 2u) * ((((t.pitch[m] + bb - 1u) / bb + 31u) / 32u + 3u) / 4u) * 256u;    // tile rows of whole super-tiles (4 tiles)
         if (bytes > (uint64_t)out_size || total * bb > (uint64_t)out_size || items > 0xFFFFFFFFull) fits = false;
         t.mip_off_bytes[m + 1] = fits ? (uint32_t)bytes : 0u;
         t.mip_off_blocks[m + 1] = fits ? (uint32_t)total : 0u;
@@ -2304,15 +2318,22 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
     return bytes == (uint64_t)out_size;                                 // :219
 }
 
-// Kernel 3 (preconditioned streams only): conditioned space -> texture space, as a gather.
-// The reference scatters byte by byte (PageDecoder.cpp:243-265,:406-444); here one thread owns
-// one block-sized chunk of one texture row, reads that block's sub-blocks from the conditioned
-// staging buffer (one typed load per sub-block) and writes the chunk with one store (or zeros for
-// row-pitch padding, which the reference leaves at the 0 of its initial memset,
-// src/BrotligDecoder.cpp:448).  Work items are tiles of 2 rows x 32 chunks, one tile per
-// wavefront: under the 2x2 swizzle the 64 blocks of a tile are consecutive in every conditioned
-// sub-stream, so the reads of a wavefront are contiguous and its writes are two 512-byte rows.
-// Streams are spread over blockIdx.y, a stream's tiles over blockIdx.x.
+// Kernel 3 (preconditioned streams only): conditioned space -> texture space.
+// The reference scatters byte by byte (PageDecoder.cpp:243-265,:406-444).  Here the work item is a SUPER-TILE of 2 texture rows x 128
+// block columns (256 blocks), one per wavefront and step:
+//   * wide path (round 5) -- a swizzled mip with even dimensions, the super-tile full of real blocks: under the 2x2 swizzle
+//     (PageDecoder.cpp:416-436) its 256 blocks are CONSECUTIVE in every conditioned sub-stream, so each sub-stream contributes one
+//     contiguous segment of 256 x sub-block-size bytes.  The wavefront reads all segments with 16-byte-per-lane loads (every load
+//     instruction 1 KiB of contiguous bytes; all of them in flight together), parks them in LDS (4 KiB, the segments back to back), and
+//     every lane then assembles four blocks from LDS -- one typed LDS read per sub-block -- and stores them, 64 lanes x 16 bytes = 1 KiB
+//     of one texture row per store instruction.  Rounds 1-4 gathered with one 1 / 2 / 4 / 6-byte load per sub-block and lane: seven load
+//     instructions for the kilobyte that now takes one, and the kernel was bound by the bytes it could keep in flight that way
+//     (profiles/r04_final_kernel_trace_stats_bc3.md: 2.45 ms for 4 GiB in + 4 GiB out, 56 % of the copy rate).
+//   * gather path -- everything else (no swizzle, odd dimensions, the last columns of a row, row-pitch padding, small mips, unknown
+//     formats): the per-block gather of rounds 1-4, two tiles of 2 x 32 blocks at a time -- one thread owns one block-sized chunk of one
+//     texture row, reads that block's sub-blocks (one typed load per sub-block) and writes the chunk with one store, or zeros for
+//     row-pitch padding, which the reference leaves at the 0 of its initial memset (src/BrotligDecoder.cpp:448).
+// Streams are spread over blockIdx.y, a stream's super-tiles over the wavefronts of blockIdx.x.
 __device__ __forceinline__ uint64_t dc_load_sub(const uint8_t* src, uint32_t sz)
 {
     uint64_t v = 0;
@@ -2326,18 +2347,12 @@ __device__ __forceinline__ uint64_t dc_load_sub(const uint8_t* src, uint32_t sz)
     }
     return v;
 }
-
-// All sub-blocks of one block (kSizes: their sizes, four bits each, first sub-block lowest -- dc_init).
+// the sub-blocks of one block, in their order, packed into the block's 16 (or 8) bytes
 template <uint32_t kSizes, uint32_t kNumSub>
-__device__ __forceinline__ void dc_gather_block(const uint8_t* cond, const DcTable& t, uint32_t gblock, uint64_t& lo, uint64_t& hi)
+__device__ __forceinline__ void dc_pack_block(const uint64_t (&v)[kNumSub], uint64_t& lo, uint64_t& hi)
 {
-    uint64_t v[kNumSub];
-#pragma unroll
-    for (uint32_t sub = 0; sub < kNumSub; ++sub) {
-        const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
-        v[sub] = dc_load_sub(cond + t.sub_stream_off[sub] + gblock * sz, sz);
-    }
     uint32_t off = 0;
+    lo = 0; hi = 0;
 #pragma unroll
     for (uint32_t sub = 0; sub < kNumSub; ++sub) {
         const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
@@ -2346,104 +2361,170 @@ __device__ __forceinline__ void dc_gather_block(const uint8_t* cond, const DcTab
         off += sz;
     }
 }
-
-// One texture, kItems work items per lane and step: ALL their loads are issued before the first is used.  The gather is bound by
-// the bytes it has in flight: reads alone take 2.04 ms of the kernel's 2.90 (4 GiB of BC3; stores alone 0.77 ms), a wavefront holds
-// 7 loads (1 KiB) per item, and at the loaded latency of ~4 us 32 wavefronts x 1 KiB per compute unit are 2.1 TB/s.
-#ifndef BROTLIG_TUNE_DC_ITEMS
-#define BROTLIG_TUNE_DC_ITEMS 2
-#endif
-template <uint32_t kSizes, uint32_t kNumSub, uint32_t kItems>
-__device__ __forceinline__ void dc_texture(const DcTable* __restrict__ tp, const uint8_t* __restrict__ cond, uint8_t* __restrict__ tex, uint32_t s, uint32_t tid, uint32_t nthreads)
+template <uint32_t kSizes, uint32_t kNumSub> constexpr uint32_t dc_sub_off(uint32_t sub)     // bytes of a block before sub-block `sub`
 {
-    // (__restrict__: the table is not what the stores below write to -- without it every table word is re-read with a vector load, and waited
-    // for, in front of the load it is the address of)
-    const DcTable& t = *tp;
-    const uint32_t bb = t.block_bytes, items = t.item_prefix[t.num_mips];
+    uint32_t off = 0;
+    for (uint32_t i = 0; i < sub && i < kNumSub; ++i) off += (kSizes >> (4u * i)) & 15u;
+    return off;
+}
+
+constexpr uint32_t kDcSuperCols = 128, kDcSuperBlocks = 2u * kDcSuperCols, kDcSuperTiles = kDcSuperCols / 32u;
+constexpr uint32_t kDcLdsBytes = kDcSuperBlocks * 16u;             // a super-tile of 16-byte blocks
+static_assert(kDcSuperTiles == 4u, "dc_init pads every tile row to whole super-tiles of four tiles");
+#ifndef BROTLIG_TUNE_DC_WIDE
+#define BROTLIG_TUNE_DC_WIDE 1          // 0: every super-tile through the gather path (A/B)
+#endif
+#ifndef BROTLIG_TUNE_DC_ASM_UNROLL
+#define BROTLIG_TUNE_DC_ASM_UNROLL 1    // blocks a lane assembles from LDS side by side (of its four per super-tile): registers against LDS latency
+#endif
+
+// Gather path: the tiles tc0 .. tc0 + kTiles - 1 (2 rows x 32 chunk columns each) of tile row `tr` of mip `m`, one chunk per lane and
+// tile: ALL the loads of all tiles are issued before the first is used (the gather is bound by the bytes it has in flight).
+template <uint32_t kSizes, uint32_t kNumSub, uint32_t kTiles>
+__device__ __forceinline__ void dc_gather_tiles(const uint32_t (&sso)[kNumSub], const uint8_t* __restrict__ cond, uint8_t* __restrict__ mip_tex,
+                                                uint32_t bb, uint32_t W, uint32_t H, uint32_t pitch, uint32_t per_row, uint32_t swizzle, uint32_t mip_block0,
+                                                uint32_t tr, uint32_t tc0, uint32_t l)
+{
+    // (the mip's geometry arrives as wave-uniform values, read from the table once per super-tile by the caller: read here, through a
+    // reference, every word was a vector load per lane)
+    uint8_t* const tex = mip_tex;
+    uint8_t* dst[kTiles];
+    uint32_t nbytes[kTiles], gblock[kTiles];
+    bool valid[kTiles], loads[kTiles];
+#pragma unroll
+    for (uint32_t u = 0; u < kTiles; ++u) {
+        valid[u] = false; loads[u] = false; dst[u] = tex; nbytes[u] = 0; gblock[u] = 0;
+        const uint32_t row = 2u * tr + ((l >> 1) & 1u), col = 32u * (tc0 + u) + 2u * (l >> 2) + (l & 1u);
+        if (row >= H || col >= per_row) continue;
+        valid[u] = true;
+        dst[u] = tex + row * pitch + col * bb;
+        nbytes[u] = min_u32(bb, pitch - col * bb);
+        if (col < W) {
+            // inverse of the 2x2 de-swizzle (PageDecoder.cpp:416-436): texture (row, col) -> block index
+            uint32_t block = row * W + col;
+            const uint32_t effW = W - (W & 1u), effH = H - (H & 1u);
+            if (swizzle && W >= 2u && H >= 2u && row < effH && col < effW) {
+                // eff = (row / 2) * 2 effW + x with x = 4 (col / 2) + 2 (row & 1) + (col & 1) < 2 effW,
+                // so eff / effW and eff % effW need one compare, not a division
+                const uint32_t x = (col >> 1) * 4u + (row & 1u) * 2u + (col & 1u);
+                const uint32_t wrap = x >= effW ? 1u : 0u;
+                block = (2u * (row >> 1) + wrap) * W + (x - (wrap ? effW : 0u));
+            }
+            gblock[u] = mip_block0 + block;
+            loads[u] = true;
+        }
+    }
+    // sub-block sizes known at compile time: every load of every tile is issued here, back to back, and waited for once
+    uint64_t v[kTiles][kNumSub];
+#pragma unroll
+    for (uint32_t u = 0; u < kTiles; ++u) {
+#pragma unroll
+        for (uint32_t sub = 0; sub < kNumSub; ++sub) {
+            const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
+            v[u][sub] = dc_load_sub(cond + sso[sub] + gblock[u] * sz, sz);     // (unconditional -- a lane without a block reads block 0 and drops
+                                                                                // it: a branch per load keeps the loads from being in flight together)
+        }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < kTiles; ++u) {
+        if (!valid[u]) continue;
+        uint64_t lo, hi;
+        dc_pack_block<kSizes, kNumSub>(v[u], lo, hi);
+        if (!loads[u]) { lo = 0; hi = 0; }                                  // row-pitch padding
+        uint8_t* const d = dst[u];
+        const bool aligned = ((uint64_t)(uintptr_t)d & (uint64_t)(bb - 1u)) == 0u;
+        if (nbytes[u] == 16u && aligned) { uint64_t q[2] = {lo, hi}; __builtin_memcpy(__builtin_assume_aligned(d, 16), q, 16); }
+        else if (nbytes[u] == 8u && bb == 8u && aligned) __builtin_memcpy(__builtin_assume_aligned(d, 8), &lo, 8);
+        else for (uint32_t i = 0; i < nbytes[u]; ++i) d[i] = (uint8_t)((i < 8u ? lo >> (8u * i) : hi >> (8u * (i - 8u))));
+    }
+}
+
+// One texture: the wavefront `wid` of `nwaves` takes every nwaves-th super-tile.  `lds`: kDcLdsBytes of this wavefront's own.
+template <uint32_t kSizes, uint32_t kNumSub>
+__device__ __forceinline__ void dc_texture(const DcTable* __restrict__ tp, const uint8_t* __restrict__ cond, uint8_t* __restrict__ tex,
+                                           uint32_t s, uint32_t wid, uint32_t nwaves, uint8_t* lds)
+{
+    // (the table -- written by the prepare kernel, constant here -- is read through the constant address space: every word a scalar load.  As
+    // plain global memory, even behind __restrict__, its words came as one vector load per lane each, waited for in front of the loads they
+    // are the addresses of, and kept in vector registers)
+    const BROTLIG_CONSTANT_AS DcTable& t = *(const BROTLIG_CONSTANT_AS DcTable*)tp;
+    constexpr uint32_t bbK = dc_sub_off<kSizes, kNumSub>(kNumSub);         // block bytes of the format: 8 or 16 (1 for the unknown format)
+    const uint32_t lane = wave::lane_id();
+    const uint32_t bb = t.block_bytes;
     uint32_t sso[kNumSub];
 #pragma unroll
     for (uint32_t sub = 0; sub < kNumSub; ++sub) sso[sub] = t.sub_stream_off[sub];
-    // Streams decoded side by side (blockIdx.y) start at different tiles: textures of the same size sit
+    // item_prefix counts lanes x tiles (64 per tile of 2 x 32 chunks), every tile row padded to whole super-tiles: >> 8 = super-tiles
+    const uint32_t supers = t.item_prefix[t.num_mips] >> 8;
+    // Streams decoded side by side (blockIdx.y) start at different super-tiles: textures of the same size sit
     // at power-of-two distances in memory, and walking them in step would hit the same HBM channels.
-    const uint32_t ntiles = items >> 6;
-    const uint32_t rot = ntiles ? ((s * 2654435761u) >> 8) % ntiles * 64u : 0u;
-    for (uint32_t item0 = tid; item0 < items; item0 += kItems * nthreads) {
-        uint8_t* dst[kItems];
-        uint32_t nbytes[kItems], gblock[kItems];
-        bool valid[kItems], loads[kItems];
+    const uint32_t rot = supers ? ((s * 2654435761u) >> 8) % supers : 0u;
+    for (uint32_t st0 = wid; st0 < supers; st0 += nwaves) {
+        // the mip and super-tile coordinates are wave-uniform and go to the scalar unit
+        const uint32_t st = wave::uniform(st0 + rot < supers ? st0 + rot : st0 + rot - supers);
+        uint32_t m = 0;
+        while ((st << 8) >= t.item_prefix[m + 1]) ++m;
+        const uint32_t W = t.w[m], H = t.h[m], pitch = t.pitch[m];
+        const uint32_t mip_bytes0 = t.mip_off_bytes[m], mip_block0 = t.mip_off_blocks[m], swizzle = t.swizzle;
+        const uint32_t per_row = (pitch + bb - 1u) / bb, tiles_x = (per_row + 31u) / 32u, supers_x = (tiles_x + kDcSuperTiles - 1u) / kDcSuperTiles;
+        const uint32_t local = st - (t.item_prefix[m] >> 8);
+        const uint32_t tr = local / supers_x, q = local - tr * supers_x;
+        const bool wide = BROTLIG_TUNE_DC_WIDE && bbK >= 8u && bb == bbK && swizzle != 0u && ((W | H) & 1u) == 0u && 2u * tr + 1u < H &&
+                          kDcSuperCols * (q + 1u) <= W && ((mip_bytes0 | pitch) & (bbK - 1u)) == 0u;
+        if (wide) {
+            if constexpr (bbK >= 8u) {
+                // first block of the super-tile in conditioned order: block(row, col) = 2 (row / 2) W + 4 (col / 2) + 2 (row & 1) + (col & 1)
+                const uint32_t g0 = mip_block0 + 2u * tr * W + kDcSuperBlocks * q;
+                constexpr uint32_t kLoads = bbK / 4u;                           // 16-byte units: 16 bbK of them, 64 per load instruction
+                Bytes16 seg[kLoads];
 #pragma unroll
-        for (uint32_t u = 0; u < kItems; ++u) {
-            const uint32_t it = item0 + u * nthreads;
-            valid[u] = false; loads[u] = false; dst[u] = tex; nbytes[u] = 0; gblock[u] = 0;
-            if (it >= items) continue;
-            const uint32_t item = it + rot < items ? it + rot : it + rot - items;
-            // a wavefront owns one tile (64 consecutive items; nthreads is a multiple of 64): the mip and tile
-            // coordinates are wave-uniform and go to the scalar unit
-            const uint32_t tile_item = wave::uniform(item & ~63u), l = item & 63u;
-            uint32_t m = 0;
-            while (tile_item >= t.item_prefix[m + 1]) ++m;
-            const uint32_t W = t.w[m], H = t.h[m], pitch = t.pitch[m];
-            const uint32_t per_row = (pitch + bb - 1u) / bb, tiles_x = (per_row + 31u) / 32u;
-            const uint32_t tile = (tile_item - t.item_prefix[m]) >> 6;
-            const uint32_t tr = tile / tiles_x, tc = tile - tr * tiles_x;
-            const uint32_t row = 2u * tr + ((l >> 1) & 1u), col = 32u * tc + 2u * (l >> 2) + (l & 1u);
-            if (row >= H || col >= per_row) continue;
-            valid[u] = true;
-            dst[u] = tex + t.mip_off_bytes[m] + row * pitch + col * bb;
-            nbytes[u] = min_u32(bb, pitch - col * bb);
-            if (col < W) {
-                // inverse of the 2x2 de-swizzle (PageDecoder.cpp:416-436): texture (row, col) -> block index
-                uint32_t block = row * W + col;
-                const uint32_t effW = W - (W & 1u), effH = H - (H & 1u);
-                if (t.swizzle && W >= 2u && H >= 2u && row < effH && col < effW) {
-                    // eff = (row / 2) * 2 effW + x with x = 4 (col / 2) + 2 (row & 1) + (col & 1) < 2 effW,
-                    // so eff / effW and eff % effW need one compare, not a division
-                    const uint32_t x = (col >> 1) * 4u + (row & 1u) * 2u + (col & 1u);
-                    const uint32_t wrap = x >= effW ? 1u : 0u;
-                    block = (2u * (row >> 1) + wrap) * W + (x - (wrap ? effW : 0u));
+                for (uint32_t i = 0; i < kLoads; ++i) {
+                    const uint32_t u = 64u * i + lane;                          // unit u = LDS bytes [16 u, 16 u + 16): the segments back to back
+                    uint32_t src = sso[0] + g0 * (kSizes & 15u) + 16u * u;
+#pragma unroll
+                    for (uint32_t sub = 1; sub < kNumSub; ++sub) {
+                        const uint32_t first = 16u * dc_sub_off<kSizes, kNumSub>(sub);         // first unit of segment `sub`
+                        const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
+                        if (u >= first) src = sso[sub] + g0 * sz + 16u * (u - first);
+                    }
+                    __builtin_memcpy(&seg[i], cond + src, 16);                  // (any byte alignment: the sub-streams start where they start)
                 }
-                gblock[u] = t.mip_off_blocks[m] + block;
-                loads[u] = true;
+#pragma unroll
+                for (uint32_t i = 0; i < kLoads; ++i) store16(lds + 16u * (64u * i + lane), seg[i]);
+                wave::sync();
+                uint8_t* const row0 = tex + mip_bytes0 + 2u * tr * pitch + kDcSuperCols * q * bbK;
+#pragma unroll BROTLIG_TUNE_DC_ASM_UNROLL
+                for (uint32_t i = 0; i < kDcSuperBlocks / 64u; ++i) {
+                    const uint32_t idx = 64u * i + lane, r = idx / kDcSuperCols, c = idx % kDcSuperCols;
+                    const uint32_t j = 4u * (c >> 1) + 2u * r + (c & 1u);       // the block's place among the super-tile's 256, conditioned order
+                    uint64_t v[kNumSub];
+#pragma unroll
+                    for (uint32_t sub = 0; sub < kNumSub; ++sub) {
+                        const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
+                        v[sub] = dc_load_sub(lds + kDcSuperBlocks * dc_sub_off<kSizes, kNumSub>(sub) + j * sz, sz);
+                    }
+                    uint64_t lo, hi;
+                    dc_pack_block<kSizes, kNumSub>(v, lo, hi);
+                    uint8_t* const d = row0 + r * pitch + c * bbK;
+                    if constexpr (bbK == 16u) { uint64_t w[2] = {lo, hi}; __builtin_memcpy(__builtin_assume_aligned(d, 16), w, 16); }
+                    else __builtin_memcpy(__builtin_assume_aligned(d, 8), &lo, 8);
+                }
+                wave::sync();                                                   // the next super-tile overwrites the segments
             }
-        }
-        // sub-block sizes known at compile time: every load of every item is issued here, back to back, and waited for once
-        uint64_t v[kItems][kNumSub];
-#pragma unroll
-        for (uint32_t u = 0; u < kItems; ++u) {
-#pragma unroll
-            for (uint32_t sub = 0; sub < kNumSub; ++sub) {
-                const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
-                v[u][sub] = dc_load_sub(cond + sso[sub] + gblock[u] * sz, sz);     // (unconditional -- a lane without a block reads block 0 and drops
-                                                                                    // it: a branch per load keeps the loads from being in flight together)
-            }
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < kItems; ++u) {
-            if (!valid[u]) continue;
-            uint64_t lo = 0, hi = 0;
-            uint32_t off = 0;
-#pragma unroll
-            for (uint32_t sub = 0; sub < kNumSub; ++sub) {
-                const uint32_t sz = (kSizes >> (4u * sub)) & 15u;
-                if (off < 8u) { lo |= v[u][sub] << (8u * off); if (off + sz > 8u) hi |= v[u][sub] >> (8u * (8u - off)); }
-                else hi |= v[u][sub] << (8u * (off - 8u));
-                off += sz;
-            }
-            if (!loads[u]) { lo = 0; hi = 0; }                                  // row-pitch padding
-            uint8_t* const d = dst[u];
-            const bool aligned = ((uint64_t)(uintptr_t)d & (uint64_t)(bb - 1u)) == 0u;
-            if (nbytes[u] == 16u && aligned) { uint64_t q[2] = {lo, hi}; __builtin_memcpy(__builtin_assume_aligned(d, 16), q, 16); }
-            else if (nbytes[u] == 8u && bb == 8u && aligned) __builtin_memcpy(__builtin_assume_aligned(d, 8), &lo, 8);
-            else for (uint32_t i = 0; i < nbytes[u]; ++i) d[i] = (uint8_t)((i < 8u ? lo >> (8u * i) : hi >> (8u * (i - 8u))));
+        } else {
+            // two tiles at a time (four at once cost more registers than their loads in flight bring: round 4, 79 VGPRs)
+#pragma nounroll
+            for (uint32_t tc = kDcSuperTiles * q; tc < kDcSuperTiles * (q + 1u) && tc < tiles_x; tc += 2u)
+                dc_gather_tiles<kSizes, kNumSub, 2u>(sso, cond, tex + mip_bytes0, bb, W, H, pitch, per_row, swizzle, mip_block0, tr, tc, lane);
         }
     }
 }
 
-__global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
+__global__ void __launch_bounds__(64) brotlig_decondition_kernel(DecodeArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t seg_lds[kDcLdsBytes];
     if (a.status[2] == 0u) return;                                      // no preconditioned stream in this batch
-    const uint32_t nthreads = gridDim.x * blockDim.x;
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nwaves = gridDim.x, wid = blockIdx.x;
     for (uint32_t s = blockIdx.y; s < a.num_streams; s += gridDim.y) {
         const DcTable& t = a.dc[s];
         if (!t.precon) continue;
@@ -2452,12 +2533,12 @@ __global__ void __launch_bounds__(256) brotlig_decondition_kernel(DecodeArgs a)
         uint8_t* tex = a.out + base;
         // per-format instantiations (sub-block sizes, four bits each, first sub-block lowest: dc_init)
         switch (t.format) {
-        case 1: dc_texture<0x422u, 3u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
-        case 2: dc_texture<0x4228u, 4u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
-        case 3: dc_texture<0x422611u, 6u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
-        case 4: dc_texture<0x611u, 3u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
-        case 5: dc_texture<0x611611u, 6u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
-        default: dc_texture<0x1u, 1u, BROTLIG_TUNE_DC_ITEMS>(&t, cond, tex, s, tid, nthreads); break;
+        case 1: dc_texture<0x422u, 3u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
+        case 2: dc_texture<0x4228u, 4u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
+        case 3: dc_texture<0x422611u, 6u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
+        case 4: dc_texture<0x611u, 3u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
+        case 5: dc_texture<0x611611u, 6u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
+        default: dc_texture<0x1u, 1u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
         }
     }
 }
@@ -2491,11 +2572,13 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
             else atomicOr(a.status, kStatusBadHeader);
             DcTable& t = a.dc[s];
             t.precon = 0;
+            t.status = ok ? 0u : kStatusBadHeader;                      // the stream's own status word (pages add kStatusBadPage)
             if (pages && si.preconditioned) {
                 // the texture described by the precondition header is the stream's output (:478): the de-conditioning
                 // kernel writes all of it, whatever happened to the stream's pages
                 if (a.scratch == nullptr || usz > 0xFFFFFFFFull || !dc_init(t, load_u32(p + 8), load_u32(p + 12), (uint32_t)usz)) {
                     t.precon = 0; pages = 0;                            // the reference has undefined behaviour here
+                    t.status = kStatusBadHeader;
                     atomicOr(a.status, kStatusBadHeader);
                 } else atomicAdd(a.status + 2, 1u);
             }
@@ -2640,8 +2723,16 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
     if (blockIdx.x >= total0 || total0 <= a.duo_limit) return;     // more wavefronts than pages: the surplus leaves before it takes a turn at the
                                                                     // page counter; all of them when the batch is the two-wavefront kernel's
     const uint32_t doubles = total0 > gridDim.x ? total0 - gridDim.x : 0u;     // wavefronts that need both halves
+    unsigned long long t_begin = 0;
+    if constexpr (kProf) t_begin = wave::realtime();         // 100 MHz, the same counter on every compute unit
     if (blockIdx.x >= doubles) decode_pages<kProf, true>(W, a, prof_lds);
     else decode_pages<kProf, false>(W, a, prof_lds);
+    if constexpr (kProf) {      // when each wavefront came and went (round 5: how long the launch's tail is -- profiles/tools/wave_times.py)
+        if (lane == 0u && a.prof != nullptr) {
+            a.prof[kNumPhases + 2u * blockIdx.x] = t_begin;
+            a.prof[kNumPhases + 2u * blockIdx.x + 1u] = wave::realtime();
+        }
+    }
 }
 
 // BROTLIG_TUNE_WAVES_PER_SIMD (diagnostics, profiles/r04_isa_stage_budget.md): the register budget of 5 (96 VGPRs) or 6 (80) wavefronts per

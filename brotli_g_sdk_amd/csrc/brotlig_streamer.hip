@@ -10,8 +10,9 @@
 // back, all asynchronously on the slot's stream, so that slot k+1's upload overlaps slot k's decode
 // and slot k-1's download (the copy engines and the compute queue run side by side).
 //
-// Layered strictly on the public C entries (BrotligDecodeBatchDevice / BrotligDecodeBatchStatus):
-// nothing here decodes, and nothing here knows the kernels.
+// Layered on the public C entries (BrotligDecodeBatchDevice / BrotligDecodeBatchStatus) plus one internal helper of the same
+// library (brotlig::enqueue_stream_status_copy, the asynchronous half of BrotligDecodeBatchStreamStatus): nothing here decodes, and
+// nothing here knows the kernels or the workspace layout.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -21,6 +22,7 @@
 
 #include "brotlig_amd.h"
 #include "brotlig_format.h"
+#include "brotlig_internal.h"
 
 using namespace brotlig;
 
@@ -37,7 +39,7 @@ struct Slot {
     hipEvent_t done = nullptr;
     uint8_t* h_in = nullptr;            // pinned: packed streams, then the descriptor array
     uint8_t* h_out = nullptr;           // pinned: decoded bytes as laid out on the device
-    uint32_t* h_status = nullptr;       // pinned: status word of the batch
+    uint32_t* h_status = nullptr;       // pinned: status word of the batch, then one status word per stream
     uint8_t* d_in = nullptr;
     uint8_t* d_out = nullptr;
     uint8_t* d_scratch = nullptr;       // allocated on the first pre-conditioned batch
@@ -50,10 +52,12 @@ struct Slot {
     std::vector<uint32_t> out_size;
     std::vector<uint8_t*> user_out;
     BROTLIG_ERROR result = BROTLIG_OK;
+    std::vector<int32_t> stream_result;         // BROTLIG_ERROR per stream, valid once the batch is finished
     // the batch this slot held before the current one, when Submit had to complete it to make room:
     // its result stays available to Wait (its outputs[] were filled at that point)
     uint64_t evicted_ticket = 0;
     BROTLIG_ERROR evicted_result = BROTLIG_OK;
+    std::vector<int32_t> evicted_stream_result;
 };
 
 }  // namespace
@@ -91,14 +95,18 @@ BROTLIG_ERROR finish(Slot& s)
     if (!s.busy) return s.result;
     BROTLIG_ERROR err = BROTLIG_OK;
     if (hipEventSynchronize(s.done) != hipSuccess) err = BROTLIG_ERROR_GENERIC;
+    auto to_error = [](uint32_t st) {                                     // same mapping as BrotligDecodeBatchStatus
+        return (st & kStatusBadHeader) ? BROTLIG_ERROR_CORRUPT_STREAM : (st & kStatusBadPage) ? BROTLIG_ERROR_GENERIC : BROTLIG_OK;
+    };
+    s.stream_result.assign(s.n, (int32_t)BROTLIG_ERROR_GENERIC);
     if (err == BROTLIG_OK) {
-        const uint32_t st = *s.h_status;
-        if (st & kStatusBadHeader) err = BROTLIG_ERROR_CORRUPT_STREAM;    // same mapping as BrotligDecodeBatchStatus
-        else if (st & kStatusBadPage) err = BROTLIG_ERROR_GENERIC;
+        err = to_error(s.h_status[0]);
+        // the undamaged streams of a batch are delivered whatever happened to their neighbours (round 5: a status word per stream)
+        for (uint32_t i = 0; i < s.n; ++i) {
+            s.stream_result[i] = (int32_t)to_error(s.h_status[1u + i]);
+            if (s.stream_result[i] == BROTLIG_OK && s.user_out[i]) memcpy(s.user_out[i], s.h_out + s.out_off[i], s.out_size[i]);
+        }
     }
-    if (err == BROTLIG_OK)
-        for (uint32_t i = 0; i < s.n; ++i)
-            if (s.user_out[i]) memcpy(s.user_out[i], s.h_out + s.out_off[i], s.out_size[i]);
     s.busy = false;
     s.result = err;
     return err;
@@ -125,7 +133,7 @@ extern "C" BROTLIG_ERROR BrotligStreamerCreate(uint32_t num_slots, uint64_t slot
                   hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess &&
                   hipHostMalloc(reinterpret_cast<void**>(&s.h_in), st->slot_in + desc_bytes + 64, hipHostMallocDefault) == hipSuccess &&
                   hipHostMalloc(reinterpret_cast<void**>(&s.h_out), st->slot_out + 64, hipHostMallocDefault) == hipSuccess &&
-                  hipHostMalloc(reinterpret_cast<void**>(&s.h_status), 64, hipHostMallocDefault) == hipSuccess &&
+                  hipHostMalloc(reinterpret_cast<void**>(&s.h_status), sizeof(uint32_t) * (1u + (size_t)max_streams_per_batch) + 64, hipHostMallocDefault) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&s.d_in), st->slot_in + desc_bytes + 64) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&s.d_out), st->slot_out + 64) == hipSuccess &&
                   hipMalloc(&s.d_ws, st->ws_bytes) == hipSuccess;
@@ -182,6 +190,7 @@ extern "C" BROTLIG_ERROR BrotligStreamerSubmit(BrotligStreamer* st, uint32_t n, 
         // are filled -- and its result is kept for a later Wait on its ticket
         s.evicted_result = finish(s);
         s.evicted_ticket = s.ticket;
+        s.evicted_stream_result = s.stream_result;
     }
     if (precon && !s.d_scratch) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.d_scratch), st->slot_out + 64));
     s.ticket = 0; s.n = 0;                                              // the slot's pinned bytes are overwritten from here on
@@ -216,6 +225,7 @@ extern "C" BROTLIG_ERROR BrotligStreamerSubmit(BrotligStreamer* st, uint32_t n, 
         if (e == BROTLIG_OK) {
             hip_ok(hipMemcpyAsync(s.h_out, s.d_out, out_pos, hipMemcpyDeviceToHost, s.stream), "download") &&
             hip_ok(hipMemcpyAsync(s.h_status, s.d_ws, sizeof(uint32_t), hipMemcpyDeviceToHost, s.stream), "status download") &&
+            hip_ok(enqueue_stream_status_copy(s.d_ws, n, s.h_status + 1, s.stream), "per-stream status download") &&
             hip_ok(hipEventRecord(s.done, s.stream), "event record");
         }
     }
@@ -238,12 +248,26 @@ extern "C" BROTLIG_ERROR BrotligStreamerWait(BrotligStreamer* st, uint64_t ticke
     return BROTLIG_ERROR_GENERIC;                                       // more than one generation old: forgotten
 }
 
+extern "C" BROTLIG_ERROR BrotligStreamerStreamResult(BrotligStreamer* st, uint64_t ticket, uint32_t index)
+{
+    if (!st || ticket == 0 || ticket >= st->next_ticket) return BROTLIG_ERROR_GENERIC;
+    Slot& s = st->slots[ticket % st->num_slots];
+    if (s.ticket == ticket) {
+        (void)finish(s);
+        return index < s.stream_result.size() ? (BROTLIG_ERROR)s.stream_result[index] : BROTLIG_ERROR_GENERIC;
+    }
+    if (s.evicted_ticket == ticket)
+        return index < s.evicted_stream_result.size() ? (BROTLIG_ERROR)s.evicted_stream_result[index] : BROTLIG_ERROR_GENERIC;
+    return BROTLIG_ERROR_GENERIC;
+}
+
 extern "C" const uint8_t* BrotligStreamerOutput(BrotligStreamer* st, uint64_t ticket, uint32_t index, uint32_t* size)
 {
     if (!st || ticket == 0 || ticket >= st->next_ticket) return nullptr;
     Slot& s = st->slots[ticket % st->num_slots];
     if (s.ticket != ticket || index >= s.n) return nullptr;
-    if (finish(s) != BROTLIG_OK) return nullptr;
+    (void)finish(s);
+    if (index >= s.stream_result.size() || s.stream_result[index] != BROTLIG_OK) return nullptr;      // a damaged stream has no bytes to show
     if (size) *size = s.out_size[index];
     return s.h_out + s.out_off[index];
 }

@@ -10,6 +10,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Read-only data written by an EARLIER kernel, read through the constant address space: a load with a wave-uniform address is then a scalar
+// load (s_load_dword into scalar registers) whatever the compiler can or cannot prove about the kernel's own stores.
+#define BROTLIG_CONSTANT_AS __attribute__((address_space(4)))
+
 namespace wave {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -30,33 +34,19 @@ __device__ __forceinline__ bool any(bool p) { return __builtin_amdgcn_ballot_w64
 // compiler lowers the ballot of a compound predicate -- also one it has folded together itself, e.g. the ballot of n > 32 where n is a
 // select -- through a 0 / 1 register and a second compare: two vector-ALU instructions per question, on a kernel bound by the vector
 // ALU.  Compound questions are asked as scalar arithmetic on these masks instead (s_and / s_or / s_andn2).
-__device__ __forceinline__ uint64_t ballot_gt(uint32_t a, uint32_t b) { uint64_t m; asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
-__device__ __forceinline__ uint64_t ballot_lt(uint32_t a, uint32_t b) { return ballot_gt(b, a); }
-__device__ __forceinline__ uint64_t ballot_ne(uint32_t a, uint32_t b) { uint64_t m; asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
-__device__ __forceinline__ uint64_t ballot_eq(uint32_t a, uint32_t b) { uint64_t m; asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b)); return m; }
-template <uint32_t K> __device__ __forceinline__ uint64_t ballot_gt_k(uint32_t a)
-{
-    uint64_t m;
-    if constexpr (K <= 64u) asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "n"(K));        // inline constant
-    else asm("v_cmp_gt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(K));                            // (VOP3 takes no literal on gfx9: a scalar register)
-    return m;
-}
-template <uint32_t K> __device__ __forceinline__ uint64_t ballot_lt_k(uint32_t a)
-{
-    uint64_t m;
-    if constexpr (K <= 64u) asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "n"(K));        // inline constant
-    else asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(K));                            // (VOP3 takes no literal on gfx9: a scalar register)
-    return m;
-}
-template <uint32_t K> __device__ __forceinline__ uint64_t ballot_eq_k(uint32_t a)
-{
-    uint64_t m;
-    if constexpr (K <= 64u) asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "n"(K));        // inline constant
-    else asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(K));                            // (VOP3 takes no literal on gfx9: a scalar register)
-    return m;
-}
-__device__ __forceinline__ uint64_t ballot_ne0(uint32_t a) { uint64_t m; asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(m) : "v"(a)); return m; }
-__device__ __forceinline__ uint64_t ballot_eq0(uint32_t a) { uint64_t m; asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(m) : "v"(a)); return m; }
+// Round 5: written with the compiler's own intrinsic (llvm.amdgcn.icmp: one v_cmp into a scalar register pair, the same
+// instruction as the inline assembly of round 4) -- the intrinsic is modelled as convergent and EXEC-dependent, an `asm` without
+// `volatile` was neither: nothing but the call sites' discipline kept the compiler from moving one across a change of the execution mask.
+// (predicates: LLVM's ICmpInst numbering -- 32 eq, 33 ne, 34 ugt, 36 ult)
+__device__ __forceinline__ uint64_t ballot_gt(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 34); }
+__device__ __forceinline__ uint64_t ballot_lt(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 36); }
+__device__ __forceinline__ uint64_t ballot_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
+__device__ __forceinline__ uint64_t ballot_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
+template <uint32_t K> __device__ __forceinline__ uint64_t ballot_gt_k(uint32_t a) { return __builtin_amdgcn_uicmp(a, K, 34); }
+template <uint32_t K> __device__ __forceinline__ uint64_t ballot_lt_k(uint32_t a) { return __builtin_amdgcn_uicmp(a, K, 36); }
+template <uint32_t K> __device__ __forceinline__ uint64_t ballot_eq_k(uint32_t a) { return __builtin_amdgcn_uicmp(a, K, 32); }
+__device__ __forceinline__ uint64_t ballot_ne0(uint32_t a) { return __builtin_amdgcn_uicmp(a, 0u, 33); }
+__device__ __forceinline__ uint64_t ballot_eq0(uint32_t a) { return __builtin_amdgcn_uicmp(a, 0u, 32); }
 // A lane mask (the same in every lane: a ballot, or scalar arithmetic on ballots) as a lane predicate: no instruction, the mask IS the
 // condition register.  Lets the compound questions of a loop be asked as s_and / s_andn2 on masks instead of per-lane logic.
 __device__ __forceinline__ bool from_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
@@ -68,6 +58,8 @@ __device__ __forceinline__ uint32_t bcast(uint32_t v, uint32_t src)
 
 // Shader clock (s_memtime), for the phase-timer diagnostics build.
 __device__ __forceinline__ unsigned long long clock() { return (unsigned long long)__builtin_readcyclecounter(); }
+// Constant-rate counter (s_memrealtime, 100 MHz), the same on every compute unit: when a wavefront came and went (diagnostics twin).
+__device__ __forceinline__ unsigned long long realtime() { return (unsigned long long)__builtin_amdgcn_s_memrealtime(); }
 
 // ---- half scope -------------------------------------------------------------------------
 // 32-bit ballot of the caller's half.

@@ -21,7 +21,9 @@ extern "C" {
  * extend 16 bytes past in_bytes, the workspace holds the per-wavefront symbol slots (+30 MiB: 8192 workgroups).  The entry points whose
  * contract changed carry the version in their SYMBOL names (the macros below), so a caller built against an older header
  * fails to link instead of passing descriptors of the wrong stride; BrotligAbiVersion() answers at run time (dlopen users).
- * Round 4 only ADDED entry points (BrotligDecodeBatchMultiDeviceAsync / ...Wait): the version stays 3. */
+ * Round 4 only ADDED entry points (BrotligDecodeBatchMultiDeviceAsync / ...Wait): the version stays 3.
+ * Round 5 likewise (BrotligDecodeBatchStreamStatus, BrotligStreamerStreamResult, BrotligDebugKnobsEnabled); the per-stream status word
+ * lives in what was padding of the workspace's per-stream record, so the workspace size and layout are those of version 3. */
 #define BROTLIG_AMD_ABI_VERSION 3
 #define BrotligDecodeWorkspaceSize      BrotligDecodeWorkspaceSize_v3
 #define BrotligDecodeWorkspaceSizeFor   BrotligDecodeWorkspaceSizeFor_v3
@@ -133,6 +135,14 @@ BROTLIG_ERROR BrotligDecodeBatchDevice(const void* d_in, uint64_t in_bytes, void
  * BROTLIG_ERROR_GENERIC (a page failed a bounds check). */
 BROTLIG_ERROR BrotligDecodeBatchStatus(const void* d_workspace, void* hip_stream);
 
+/* Per-stream results of the last batch that used `d_workspace` (round 5).  The reference's only result is per CALL, one stream per call
+ * (src/BrotligDecoder.cpp:437-446); its shader's queue of up to 4 096 streams (src/decoder/BrotliGCompute.hlsl:1757-1881) has no way to say
+ * WHICH asset of a dispatch was damaged.  Waits for `hip_stream`, then results[i] = BROTLIG_OK, BROTLIG_ERROR_CORRUPT_STREAM (stream i's
+ * header was refused: none of its pages was decoded) or BROTLIG_ERROR_GENERIC (a page of stream i failed a bounds check: that page's
+ * bytes are undefined, the stream's other pages and every other stream are as decoded).  `results` is a HOST array of `num_streams`
+ * (the count the batch was enqueued with).  Returns what BrotligDecodeBatchStatus returns for the batch. */
+BROTLIG_ERROR BrotligDecodeBatchStreamStatus(const void* d_workspace, uint32_t num_streams, int32_t* results, void* hip_stream);
+
 /* Benchmark helper: runs the batch `warmup` + `steps` times on `hip_stream` and reports
  *   *total_ms        wall time of the `steps` timed passes (HIP events on hip_stream)
  *   *decode_kernel_ms average duration of the page-decode kernel alone over the timed passes
@@ -195,7 +205,9 @@ BROTLIG_ERROR BrotligDeviceSelfTest(void);
  * per-phase shader-clock sums over all page pairs (s_memtime deltas of lane 0 of every wave).
  * cycles_out[0..11] = setup, tables, commands, ring, positions, literals, copy-fence, copy-levels,
  * delta, total, number of rounds, number of copy levels, then the level sub-phases (wide short
- * copies, byte-wise copies, long copies) and rounds assembled in global memory.  Synchronous. */
+ * copies, byte-wise copies, long copies) and rounds assembled in global memory.  Synchronous.
+ * Round 5: entries beyond the phase sums (27 of them; api.py BatchDecoder.PHASES) are {first, last} tick of a 100 MHz counter for
+ * every wavefront of the launch, 2 x BrotligKernelGridSize() values: how the launch ramps up and how long its tail is. */
 BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
                                         const BrotligStreamDesc* d_streams, uint32_t num_streams,
                                         void* d_workspace, size_t workspace_bytes, void* d_scratch,
@@ -227,8 +239,17 @@ BROTLIG_ERROR BrotligStreamerSubmit(BrotligStreamer* streamer, uint32_t num_stre
                                     uint64_t* ticket);
 BROTLIG_ERROR BrotligStreamerWait(BrotligStreamer* streamer, uint64_t ticket);
 const uint8_t* BrotligStreamerOutput(BrotligStreamer* streamer, uint64_t ticket, uint32_t index, uint32_t* size);
+/* Round 5: the result of ONE stream of a batch (BrotligDecodeBatchStreamStatus for the streaming caller).  When Wait reports an error the
+ * batch's undamaged streams are still delivered -- their outputs[] are filled, BrotligStreamerOutput returns their bytes -- and this names
+ * the damaged ones: BROTLIG_OK / BROTLIG_ERROR_CORRUPT_STREAM / BROTLIG_ERROR_GENERIC for stream `index` of the batch; waits for the batch
+ * like Wait; BROTLIG_ERROR_GENERIC for a ticket or index it does not know (valid as long as Wait is: the batch in the slot, or the one it
+ * displaced). */
+BROTLIG_ERROR BrotligStreamerStreamResult(BrotligStreamer* streamer, uint64_t ticket, uint32_t index);
 
-/* Diagnostics, for tests: decode with exactly `workgroups` wavefronts (0 = the normal rule: one per page while the batch has no more
+/* Diagnostics, for tests.  Both switches below are INERT unless the process was started with BROTLIG_ENABLE_DEBUG_KNOBS=1 in its
+ * environment (read once; BrotligDebugKnobsEnabled() answers): a production process cannot have its kernel selection changed by a stray
+ * call or a forgotten reset.
+ * Decode with exactly `workgroups` wavefronts (0 = the normal rule: one per page while the batch has no more
  * pages than the device holds wavefronts, the full grid otherwise), so that a small batch can exercise the two-pages-per-wavefront
  * path as well as the one-page path it gets by default.  Process-wide. */
 void BrotligDebugSetDecodeGrid(uint32_t workgroups);
@@ -236,6 +257,7 @@ void BrotligDebugSetDecodeGrid(uint32_t workgroups);
  * for batches of up to 2 048 pages, one wavefront per one or two pages otherwise), 1 = never the two-wavefront
  * kernel, 2 = always.  Process-wide. */
 void BrotligDebugSetDecodeMode(uint32_t mode);
+uint32_t BrotligDebugKnobsEnabled(void);
 
 /* Static properties, for reports: LDS bytes per workgroup, workgroups launched. */
 uint32_t BrotligKernelLdsBytes(void);

@@ -58,6 +58,7 @@ struct __attribute__((aligned(16))) EntropyLds {       // one per 32-lane half
     uint16_t limit[3][16] __attribute__((aligned(16)));
     uint32_t first_offs[3][16];
     uint32_t page_params;
+    uint32_t page_stream;
     uint32_t ring[8] __attribute__((aligned(16)));
 };
 static_assert(kLutBitsIcp == 8 && kLutBitsDist == 8 && kLutBitsLit == 8, "build areas are laid out for three 512-byte LUTs");

@@ -31,6 +31,7 @@ def main():
         streams, expected = bench.build_streams(w, list(range(256 if w == "bc3" else 16)), 256 if w == "bc3" else 4096, 8 if w == "bc3" else 256)
         out_sizes = [len(e) for e in expected] if w == "bc3" else None
         per = {n: [] for n in names}
+        rest = {}
         exact = {}
         for rep in range(a.reps):
             for n, so in zip(names, libs):
@@ -47,6 +48,8 @@ def main():
                     exact[n] = ok
                 total, kern = dec.timed(2, a.steps)
                 per[n].append(kern if w != "bc3" else total / a.steps)
+                if w == "bc3":      # what the step takes beside the page kernel: prepare + de-conditioning
+                    rest.setdefault(n, []).append(total / a.steps - kern)
                 U = dec.decompressed_bytes
                 del dec
                 torch.cuda.empty_cache()
@@ -55,6 +58,9 @@ def main():
             best = min(per[n])
             results.setdefault(w, {})[n] = {"ms": [round(x, 4) for x in per[n]], "best_ms": round(best, 4), "GBps": round(U / best / 1e6, 1),
                                             "vs_base_pct": round((base / best - 1) * 100, 2), "bit_exact": exact[n]}
+            if n in rest:
+                results[w][n]["step_minus_page_kernel_ms"] = round(min(rest[n]), 4)
+                print(f"{w:10s} {n:28s} step - page kernel (prepare + de-conditioning): {min(rest[n]):.4f} ms", flush=True)
             print(f"{w:10s} {n:28s} best {best:8.4f} ms  {U / best / 1e6:7.1f} GB/s  {100 * (base / best - 1):+6.2f} %  exact {exact[n]}  runs {[round(x, 3) for x in per[n]]}", flush=True)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)

@@ -9,7 +9,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cs=$root/brotli_g_sdk_amd/csrc
 build() { local name=$1; shift
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/include" -I "$cs" "$@" -o "$out/lib_$name.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"; }
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/profiles/experiments/split_path" -I "$root/include" -I "$cs" "$@" -o "$out/lib_$name.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"; }
 build regs
 build regs_padded -DBROTLIG_E_PAD_LDS
 build ring -DBROTLIG_E_RING=1

@@ -11,7 +11,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cs=$root/brotli_g_sdk_amd/csrc
 build() { # name E L
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/include" -I "$cs" -DBROTLIG_E_WAVES=$2 -DBROTLIG_L_WAVES=$3 \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/profiles/experiments/split_path" -I "$root/include" -I "$cs" -DBROTLIG_E_WAVES=$2 -DBROTLIG_L_WAVES=$3 \
         -o "$out/lib_$1.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"
 }
 build e5l5 5 5; build e5l6 5 6; build e5l8 5 8; build e4l6 4 6

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 cs=$root/brotli_g_sdk_amd/csrc
 build() { # name flags...
   local name=$1; shift
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/include" -I "$cs" "$@" -o "$out/lib_$name.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/profiles/experiments/split_path" -I "$root/include" -I "$cs" "$@" -o "$out/lib_$name.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"
 }
 build p2 -DBROTLIG_E_WAVES=5 -DBROTLIG_L_WAVES=5 -DBROTLIG_L_PREFETCH=2
 build p1 -DBROTLIG_E_WAVES=5 -DBROTLIG_L_WAVES=5 -DBROTLIG_L_PREFETCH=1

@@ -8,7 +8,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cs=$root/brotli_g_sdk_amd/csrc
 build() { local name=$1; shift
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/include" -I "$cs" "$@" -o "$out/lib_$name.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"; }
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/profiles/experiments/split_path" -I "$root/include" -I "$cs" "$@" -o "$out/lib_$name.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"; }
 build g8 -DBROTLIG_G_WAVES=8
 build g6 -DBROTLIG_G_WAVES=6
 ( export BROTLIG_SPLIT=2 BROTLIG_HIP_SO="$out/lib_g8.so"; python -m pytest tests/test_gpu_decode.py tests/test_gpu_differential.py -m gpu -q ) > "$out/pytest_split2.log" 2>&1

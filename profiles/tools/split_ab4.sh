@@ -8,7 +8,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 cs=$root/brotli_g_sdk_amd/csrc
 build() { local name=$1; shift
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/include" -I "$cs" "$@" -o "$out/lib_$name.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"; }
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_WITH_SPLIT -I "$root/profiles/experiments/split_path" -I "$root/include" -I "$cs" "$@" -o "$out/lib_$name.so" "$cs/brotlig_hip.hip" "$cs/brotlig_streamer.hip" 2>> "$out/build.err"; }
 build p4 -DBROTLIG_PAGE_WAVES=4
 build p8 -DBROTLIG_PAGE_WAVES=8
 build p16 -DBROTLIG_PAGE_WAVES=16

@@ -78,6 +78,14 @@ def precon_cases():
         ("bc3_wide_swz_mips2", 3, 320, 6, 2, 1, 1, 0, 0),         # several 128-block steps per row pair, the last one partial (quad de-conditioning)
         ("bc1_mips_6_3_2", 1, 6, 6, 3, 1, 1, 0, 0),               # an even mip behind an odd one: its rows start 8 bytes off a 16-byte boundary
         ("bc4_swz_200x2", 4, 200, 2, 1, 1, 0, 0, 0),
+        # round 5, the de-conditioning kernel's wide path (super-tiles of 2 x 128 blocks read as contiguous segments through LDS) next to its
+        # gather path, for every block layout: row padding of whole blocks behind wide tiles, mips that stop being wide, a pitch that is
+        # no multiple of the block size (gather only), eight-byte blocks
+        ("bc2_wide_pitchpad", 2, 256, 4, 1, 1, 1, 0, 256 * 16 + 48),
+        ("bc5_wide_mips3_aligned", 5, 384, 8, 3, 1, 1, 1, 0),
+        ("bc3_wide_odd_pitch", 3, 128, 4, 1, 1, 0, 0, 128 * 16 + 7),
+        ("bc4_wide_mips2", 4, 256, 6, 2, 1, 1, 0, 0),
+        ("bc1_wide_tall", 1, 640, 34, 1, 1, 0, 0, 0),
     ]:
         pre = dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=swz, delta=delta,
                    pitch_d3d12_aligned=aligned, pitch_bytes=pitch)

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the library's two diagnostics switches (which decode kernel, which grid) only work in a process that asks for them in its environment
+# BEFORE the library's first launch: the parity matrix below pins each form of the page kernel in turn
+os.environ.setdefault("BROTLIG_ENABLE_DEBUG_KNOBS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -61,3 +65,27 @@ def _decode_mode_from_env():
         from brotli_g_sdk_amd import api
         api.DebugSetDecodeMode(mode)
     yield
+
+
+# The forms of the page decode a batch can meet on the device (csrc/brotlig_hip.hip enqueue(), csrc/brotlig_kernels.h decode_kernel_body):
+#   rule  -- what the size rule picks; for the small batches of the parity cases that is brotlig_decode_duo_kernel (two wavefronts per page)
+#   solo  -- brotlig_decode_kernel, one page per wavefront: decode_pages<.., true>, the one-page window geometry, 64-lane copy teams
+#   pair  -- brotlig_decode_kernel forced onto ONE wavefront: decode_pages<.., false>, two pages per wavefront, one per 32-lane half -- the
+#            form every large batch (the benchmark) runs.  A batch needs at least two pages for it, so single-stream cases go through
+#            BatchDecoder with a companion stream (helpers: decode_all_forms below).
+KERNEL_FORMS = (("rule", 0, 0), ("solo", 1, 0), ("pair", 1, 1))
+
+
+@pytest.fixture(params=KERNEL_FORMS, ids=[f[0] for f in KERNEL_FORMS])
+def kernel_form(request):
+    """Pins the decode kernel form for one test and puts the size rule back afterwards (the whole oracle-parity matrix on
+    every form of the page kernel, under the driver's plain `pytest -m gpu`)."""
+    name, mode, grid = request.param
+    from brotli_g_sdk_amd import api
+    api.DebugSetDecodeMode(mode)
+    api.DebugSetDecodeGrid(grid)
+    try:
+        yield name
+    finally:
+        api.DebugSetDecodeGrid(0)
+        api.DebugSetDecodeMode(int(os.environ.get("BROTLIG_TEST_DECODE_MODE", "0")))

@@ -151,3 +151,37 @@ def simple_code_one_symbol():
                 bad[at] &= np.uint8(0xF3)                           # NSYM - 1 field (bits 2..3) <- 0
                 return bad, len(data)
     raise AssertionError("no input produced a simple ICP code")
+
+
+def damaged_batch_for_stream_status(n=64, seed=5):
+    """A batch of `n` small valid streams of every data class with THREE of them damaged in three different ways, for the per-stream
+    status (BrotligDecodeBatchStreamStatus): returns (streams, output sizes, source bytes or None for the damaged ones,
+    {index: expected kStatus bit}) -- 1 = header refused by the prepare kernel, 2 = a page failed.
+      * a page table entry that points far outside the stream: the page is refused when it is fetched (fetch_job);
+      * a prefix-code description the format does not define (simple_code_one_symbol): the page is refused after its table build, at
+        page end -- the other flagging path;
+      * a stream whose page table does not fit its own bytes (header says 40 000 pages): refused as a whole by the prepare kernel."""
+    rng = np.random.default_rng(seed)
+    makers = [D.text, D.records, D.samples16, D.runs, D.mixed, D.random_bytes]
+    streams, sizes, datas = [], [], []
+    for i in range(n):
+        size = int(rng.integers(1, 3 * 65536))
+        d = makers[i % len(makers)](size, 1000 + i)
+        streams.append(E.encode(d)); sizes.append(len(d)); datas.append(d)
+    expect = {}
+    # (a) page table damage in a stream of at least two pages
+    a = next(i for i in range(7, n) if sizes[i] > 65536 and i % len(makers) != 5)
+    bad = streams[a].copy()
+    bad[8 + 4:8 + 8] = np.frombuffer(np.uint32(0x7FFFFFF0).tobytes(), np.uint8)      # offset of page 1
+    streams[a] = bad; datas[a] = None; expect[a] = 2
+    # (b) an undefined code description in the first page
+    b = a + 11
+    sbad, cap = simple_code_one_symbol()
+    streams[b] = sbad; sizes[b] = cap; datas[b] = None; expect[b] = 2
+    # (c) a header whose page table cannot lie inside the stream
+    c = a + 23
+    hb = streams[c].copy()
+    hb[2] = 40000 & 0xFF; hb[3] = 40000 >> 8
+    streams[c] = hb; datas[c] = None; expect[c] = 1
+    assert len({a, b, c}) == 3 and max(a, b, c) < n
+    return streams, sizes, datas, expect

@@ -4,6 +4,8 @@
 #pragma once
 #include "sim_runtime.h"
 
+#define BROTLIG_CONSTANT_AS
+
 namespace wave {
 
 inline uint32_t lane_id() { return sim::lane_now() & 63u; }
@@ -12,6 +14,7 @@ inline uint32_t lane_id_fresh() { return lane_id(); }
 #define SIM_SITE int site = __builtin_LINE()
 
 inline unsigned long long clock() { return (unsigned long long)__builtin_ia32_rdtsc(); }
+inline unsigned long long realtime() { return (unsigned long long)__builtin_ia32_rdtsc(); }
 inline uint64_t ballot64(bool p, SIM_SITE)
 {
     const int s = sim::collective_enter(p ? 1 : 0, 0, site);

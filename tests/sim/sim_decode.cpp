@@ -6,7 +6,9 @@
 #include <brotlig_wave_ops.h>
 
 #include "brotlig_kernels.h"
-#include "experimental/brotlig_split_kernels.h"
+#ifdef BROTLIG_WITH_SPLIT       // the two-kernel experiment of round 3 (profiles/experiments/split_path/): only tests/test_sim_split.py builds it in
+#include "brotlig_split_kernels.h"
+#endif
 
 using namespace brotlig;
 
@@ -24,6 +26,17 @@ extern "C" void sim_set_duo(int on) { g_duo = on; }
 extern "C" uint64_t sim_duo_launches() { return g_duo_launches; }
 static void decond_body(void* p) { brotlig_decondition_kernel(*(DecodeArgs*)p); }
 static void selftest_body(void* p) { brotlig_selftest_kernel((uint32_t*)p); }
+// the last batch's per-stream status words (DcTable::status; BrotligDecodeBatchStreamStatus reads the same words on the device)
+static std::vector<uint32_t> g_stream_status;
+extern "C" uint32_t sim_stream_status(uint32_t i) { return i < g_stream_status.size() ? g_stream_status[i] : 0xFFFFFFFFu; }
+// Host rule (csrc/brotlig_hip.hip enqueue()): 0 = one kernel pinned by sim_set_duo, otherwise the page limit up to which a batch belongs to the
+// two-wavefront kernel -- BOTH kernels are then run back to back, each decides by DecodeArgs::duo_limit, and the policy kernel is skipped
+// when no two pages can meet in a wavefront, exactly as the host does it.
+static uint32_t g_host_rule_limit = 0;
+static uint32_t g_pages_by_duo = 0, g_pages_by_classic = 0;     // what each kernel took from the page counter in the last batch
+extern "C" void sim_set_host_rule(uint32_t duo_limit) { g_host_rule_limit = duo_limit; }
+extern "C" uint32_t sim_counter_after_duo() { return g_pages_by_duo; }
+extern "C" uint32_t sim_counter_after_classic() { return g_pages_by_classic; }
 
 extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* out, uint64_t out_bytes,
                                 uint8_t* scratch, const uint64_t* in_offsets, const uint64_t* out_offsets,
@@ -50,15 +63,30 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     a.far_syms = far_syms.data();
     sim::run_grid(1, prepare_body, &a);
     if (a.order) { sim::run_grid(3, order_count_body, &a); sim::run_grid(3, order_scatter_body, &a); }
-    sim::run_grid(1, policy_body, &a);
-    if (g_duo) { ++g_duo_launches; a.duo_limit = 0xFFFFFFFFu; sim::run_grid(decode_grid, duo_body, &a, 2); a.duo_limit = 0u; }
-    else sim::run_grid(decode_grid, decode_body, &a);
+    if (g_host_rule_limit) {
+        // as enqueue(): the policy kernel only when two pages can meet in a wavefront; both decode kernels, the device decides
+        const uint64_t bound = out_bytes / kMinPageSize + num_streams;
+        if (bound > (uint64_t)decode_grid) sim::run_grid(1, policy_body, &a);
+        a.duo_limit = g_host_rule_limit;
+        ++g_duo_launches;
+        sim::run_grid(decode_grid, duo_body, &a, 2);
+        g_pages_by_duo = counter;
+        sim::run_grid(decode_grid, decode_body, &a);
+        g_pages_by_classic = counter - g_pages_by_duo;
+    } else {
+        sim::run_grid(1, policy_body, &a);
+        if (g_duo) { ++g_duo_launches; a.duo_limit = 0xFFFFFFFFu; sim::run_grid(decode_grid, duo_body, &a, 2); a.duo_limit = 0u; }
+        else sim::run_grid(decode_grid, decode_body, &a);
+    }
     sim::run_grid(3, decond_body, &a);
     *status_out = status_words[0];
     g_last_policy = status_words[3];
+    g_stream_status.resize(num_streams);
+    for (uint32_t i = 0; i < num_streams; ++i) g_stream_status[i] = dc[i].status;
     return 0;
 }
 
+#ifdef BROTLIG_WITH_SPLIT
 static void entropy_body(void* p) { brotlig_entropy_kernel(*(DecodeArgs*)p); }
 static void assemble_body(void* p) { brotlig_assemble_kernel(*(DecodeArgs*)p); }
 static void assemble_global_body(void* p) { brotlig_assemble_global_kernel(*(DecodeArgs*)p); }
@@ -100,6 +128,7 @@ extern "C" int sim_entropy_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* 
     *status_out = status_words[0];
     return 0;
 }
+#endif  // BROTLIG_WITH_SPLIT
 
 extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word 3: pairing policy chosen by the prepare kernel
 extern "C" void sim_set_order(int on) { g_use_order = on; }

@@ -137,3 +137,18 @@ def test_multi_device_entry_checks_its_arguments_without_a_device():
         assert fn(None, 1, ctypes.sizeof(api.DeviceBatch)) != 0
         assert fn(ctypes.addressof(arr), 1, ctypes.sizeof(api.DeviceBatch) - 8) != 0
         assert fn(ctypes.addressof(arr), 0, ctypes.sizeof(api.DeviceBatch)) != 0
+
+
+def test_debug_knobs_are_inert_without_the_environment_switch():
+    """BrotligDebugSetDecodeMode / ...Grid are process-wide; they only work in a process started with
+    BROTLIG_ENABLE_DEBUG_KNOBS=1 (tests/conftest.py).  A process without it: the library says so, the Python mirror refuses."""
+    import subprocess
+    import sys
+    code = ("import os; os.environ.pop('BROTLIG_ENABLE_DEBUG_KNOBS', None)\n"
+            "from brotli_g_sdk_amd import api\n"
+            "assert not api.DebugKnobsEnabled()\n"
+            "try:\n    api.DebugSetDecodeMode(2)\n    raise SystemExit(3)\nexcept RuntimeError:\n    pass\n"
+            "api.DebugSetDecodeMode(0)\n")
+    env = {k: v for k, v in os.environ.items() if k != "BROTLIG_ENABLE_DEBUG_KNOBS"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=env).returncode == 0

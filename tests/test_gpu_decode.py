@@ -25,29 +25,58 @@ def api():
     return a
 
 
+_COMPANION = []
+
+
+def _companion():
+    """A stream of another kind (text, two pages) that shares the wavefront with the case under test in the two-pages-per-wavefront form."""
+    if not _COMPANION:
+        d = D.text(65536 + 4321, 99)
+        _COMPANION.append((d, E.encode(d)))
+    return _COMPANION[0]
+
+
+def decode_in_form(api, form, stream, out_size=None):
+    """The decoded bytes of `stream` under the kernel form the `kernel_form` fixture has pinned (tests/conftest.py).  `rule` and `solo` go
+    through the host-pointer entry (DecodeGPU), like a caller of the reference; `pair` -- two pages per wavefront, the form of every large
+    batch -- needs more than one page in the launch: the stream twice, a companion of another kind between them, one wavefront for all."""
+    if form != "pair":
+        out, ms = api.DecodeGPU(stream, output_size=out_size)
+        assert ms > 0.0
+        return out
+    comp_d, comp_s = _companion()
+    n = int(api.DecompressedSize(stream)) if out_size is None else int(out_size)
+    dec = api.BatchDecoder([stream, comp_s, stream], out_sizes=[n, len(comp_d), n])
+    dec.poison_output()
+    dec.decode()
+    assert np.array_equal(dec.output(1), comp_d), "the companion stream"
+    first, second = dec.output(0), dec.output(2)
+    assert np.array_equal(first, second), "the same stream twice in one launch"
+    return first
+
+
 def test_wave_primitives_on_device(api):
     """DPP half-wave scan vs shuffle scan, half ballot / shuffle / max, checked on the host."""
     api.DeviceSelfTest()
 
 
 @pytest.mark.parametrize("name,thunk,kw", plain_cases(), ids=[c[0] for c in plain_cases()])
-def test_decode_gpu_plain(api, name, thunk, kw):
+def test_decode_gpu_plain(api, kernel_form, name, thunk, kw):
     data = thunk()
     stream = E.encode(data, **kw)
     rc, ref = oracle_decode(stream)
     assert rc == 0 and np.array_equal(ref, data)
-    out, ms = api.DecodeGPU(stream)
+    out = decode_in_form(api, kernel_form, stream)
     assert len(out) == len(ref) and np.array_equal(out, ref)
-    assert ms > 0.0
 
 
 @pytest.mark.parametrize("name,thunk,pre", precon_cases(), ids=[c[0] for c in precon_cases()])
-def test_decode_gpu_preconditioned(api, name, thunk, pre):
+def test_decode_gpu_preconditioned(api, kernel_form, name, thunk, pre):
     tex = thunk()
     stream = E.encode(tex, precondition=pre)
     rc, ref = oracle_decode(stream, out_size=len(tex))
     assert rc == 0 and np.array_equal(ref, tex)
-    out, _ = api.DecodeGPU(stream, output_size=len(tex))
+    out = decode_in_form(api, kernel_form, stream, out_size=len(tex))
     assert np.array_equal(out, ref)
 
 
@@ -80,7 +109,7 @@ def test_far_copies_read_what_the_previous_group_flushed(api, name, thunk, kw):
 
 
 @pytest.mark.parametrize("name,thunk,kw", symbol_overflow_cases(), ids=[c[0] for c in symbol_overflow_cases()])
-def test_prefix_codes_with_more_symbols_than_the_lds_arrays_hold(api, name, thunk, kw):
+def test_prefix_codes_with_more_symbols_than_the_lds_arrays_hold(api, kernel_form, name, thunk, kw):
     """~300 distinct ICP or distance symbols in a page: the decoder keeps the first 255 / 96 (canonical order) in LDS
     and reads the rest from its workspace.  Several copies side by side, decoded twice: the global slots are reused
     page after page and must never serve a previous page's symbols."""
@@ -97,12 +126,19 @@ def test_prefix_codes_with_more_symbols_than_the_lds_arrays_hold(api, name, thun
             assert np.array_equal(dec.output(i), ref), (name, i)
 
 
-def test_golden_fixtures_on_gpu(api):
+def test_golden_fixtures_on_gpu(api, kernel_form):
     index = json.load(open(os.path.join(GOLDEN, "index.json")))
-    for name, meta in index.items():
-        stream = np.fromfile(os.path.join(GOLDEN, name + ".brotlig"), dtype=np.uint8)
-        out, _ = api.DecodeGPU(stream, output_size=meta["size"])
-        assert hashlib.sha256(out.tobytes()).hexdigest() == meta["sha256"], name
+    names = sorted(index)
+    streams = [np.fromfile(os.path.join(GOLDEN, name + ".brotlig"), dtype=np.uint8) for name in names]
+    if kernel_form == "pair":       # all fixtures in ONE launch on one wavefront: pages of unrelated fixtures side by side in its two halves
+        dec = api.BatchDecoder(streams, out_sizes=[index[n]["size"] for n in names])
+        dec.poison_output()
+        dec.decode()
+        outs = [dec.output(i) for i in range(len(names))]
+    else:
+        outs = [api.DecodeGPU(s, output_size=index[n]["size"])[0] for n, s in zip(names, streams)]
+    for name, out in zip(names, outs):
+        assert hashlib.sha256(out.tobytes()).hexdigest() == index[name]["sha256"], (name, kernel_form)
 
 
 def test_error_codes(api):
@@ -405,3 +441,51 @@ def test_simple_code_with_one_symbol_rejects_the_page_on_device(api):
     with pytest.raises(api.BrotligError):
         dec.decode()
     assert np.all(dec.output(0) == 0xCD) and np.array_equal(dec.output(1), good)
+
+
+def test_per_stream_status_names_the_damaged_streams(api, kernel_form):
+    """BrotligDecodeBatchStreamStatus (round 5): a 64-stream batch with three streams damaged in three ways -- a page refused when it is
+    fetched, a page refused at its end, a stream refused by the prepare kernel -- names exactly those three, with the reference's error codes,
+    in every form of the page kernel; the other 61 streams are bit-exact."""
+    from fuzzcases import damaged_batch_for_stream_status
+    streams, sizes, datas, expect = damaged_batch_for_stream_status()
+    dec = api.BatchDecoder(streams, out_sizes=sizes)
+    dec.poison_output()
+    with pytest.raises(api.BrotligError):
+        dec.decode()
+    rc, per = dec.stream_status()
+    assert rc == api.BROTLIG_ERROR_CORRUPT_STREAM                    # the batch-wide answer: the header failure wins, as before
+    want = {i: (api.BROTLIG_ERROR_CORRUPT_STREAM if bit == 1 else api.BROTLIG_ERROR_GENERIC) for i, bit in expect.items()}
+    assert {i: r for i, r in enumerate(per) if r != api.BROTLIG_OK} == want
+    for i, d in enumerate(datas):
+        if d is not None:
+            assert np.array_equal(dec.output(i), d), i
+    # a clean batch afterwards in the same workspace: every word is back to OK
+    good = [s for s, d in zip(streams, datas) if d is not None][:5]
+    dec2 = api.BatchDecoder(good)
+    dec2.decode()
+    assert dec2.stream_status() == (api.BROTLIG_OK, [api.BROTLIG_OK] * 5)
+
+
+def test_streamer_reports_the_damaged_stream_and_delivers_the_others(api):
+    """BrotligStreamerStreamResult (round 5): Wait still fails for a batch with a damaged stream, but the batch's other streams are
+    delivered (outputs[] filled, BrotligStreamerOutput serves them) and the damaged one is named."""
+    from fuzzcases import simple_code_one_symbol
+    bad, cap = simple_code_one_symbol()
+    datas = [D.text(70000, 1), None, D.mixed(3 * 65536 + 5, 2), D.runs(65536, 3)]
+    streams = [E.encode(d) if d is not None else bad for d in datas]
+    st = api.Streamer(slots=2, slot_in_bytes=2 << 20, slot_out_bytes=4 << 20, max_streams=8)
+    outs = [np.full(len(d) if d is not None else cap, 0xAB, np.uint8) for d in datas]
+    t = st.submit(streams, outs)
+    with pytest.raises(api.BrotligError):
+        st.wait(t)
+    assert st.stream_results(t, 4) == [api.BROTLIG_OK, api.BROTLIG_ERROR_GENERIC, api.BROTLIG_OK, api.BROTLIG_OK]
+    for d, o in zip(datas, outs):
+        if d is not None:
+            assert np.array_equal(o, d)
+    assert np.all(outs[1] == 0xAB)                                   # nothing of the damaged stream is handed over
+    assert st.output(t, 1) is None and np.array_equal(st.output(t, 2), datas[2])
+    t2 = st.submit([streams[0]])                                     # the streamer goes on
+    assert np.array_equal(st.result(t2)[0], datas[0])
+    st.close()
+

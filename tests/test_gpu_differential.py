@@ -27,7 +27,7 @@ def api():
 
 
 @pytest.mark.parametrize("chunk", range(0, N_PLAIN, 44))
-def test_random_streams_batched(api, chunk):
+def test_random_streams_batched(api, kernel_form, chunk):
     """44 random streams per launch (pages of unrelated streams share wavefronts), each compared with the oracle."""
     datas, streams = [], []
     for seed in range(chunk, chunk + 44):
@@ -52,7 +52,7 @@ def test_random_streams_single_asset_entry(api, seed):
     assert np.array_equal(out, d), (seed, kw)
 
 
-def test_random_preconditioned_streams(api):
+def test_random_preconditioned_streams(api, kernel_form):
     texs, streams = [], []
     for seed in range(N_PRECON):
         tex, pre, kw = random_precon(seed)

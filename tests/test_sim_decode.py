@@ -18,7 +18,10 @@ SIM_DIR = os.path.join(ROOT, "tests", "sim")
 CSRC = os.path.join(ROOT, "brotli_g_sdk_amd", "csrc")
 
 
-def build_sim(name, flags=()):
+SPLIT_DIR = os.path.join(ROOT, "profiles", "experiments", "split_path")
+
+
+def build_sim(name, flags=(), split=False):
     # BROTLIG_SIM_FLAGS="-DBROTLIG_TUNE_X=1 ...": the whole simulator suite on a non-default build of the kernel source
     # (how the A/B variants of profiles/tools/ab_variants.sh are checked for bit-exactness before they go to the GPU box)
     extra = os.environ.get("BROTLIG_SIM_FLAGS", "").split()
@@ -29,10 +32,13 @@ def build_sim(name, flags=()):
     so = os.path.join(SIM_DIR, name)
     srcs = [os.path.join(SIM_DIR, f) for f in ("sim_decode.cpp", "sim_runtime.cpp")]
     deps = srcs + [os.path.join(SIM_DIR, f) for f in ("sim_runtime.h", "brotlig_wave_ops.h")] + \
-        [os.path.join(CSRC, f) for f in ("brotlig_kernels.h", "experimental/brotlig_split_kernels.h", "brotlig_format.h")]
+        [os.path.join(CSRC, f) for f in ("brotlig_kernels.h", "brotlig_format.h")]
+    if split:       # the two-kernel experiment of round 3 lives with the other experiments, outside the package (tests/test_sim_split.py)
+        deps.append(os.path.join(SPLIT_DIR, "brotlig_split_kernels.h"))
+        flags = list(flags) + ["-DBROTLIG_WITH_SPLIT", "-I", SPLIT_DIR]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         tmp = f"{so}.{os.getpid()}.tmp"             # built aside and moved into place: pytest-xdist workers may get here together
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DBROTLIG_WITH_SPLIT", "-I", SIM_DIR, "-I", CSRC, "-o", tmp] + list(flags) + srcs)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-I", SIM_DIR, "-I", CSRC, "-o", tmp] + list(flags) + srcs)
         os.replace(tmp, so)
     L = ctypes.CDLL(so)
     L.sim_decode_batch.restype = ctypes.c_int
@@ -247,3 +253,47 @@ def test_sim_simple_code_with_one_symbol_rejects_the_page(sim):
     assert status & 2                                               # kStatusBadPage
     assert np.all(outs[0] == 0xCD)                                  # nothing of the rejected page reached the output
     assert np.array_equal(outs[1], good_data)
+
+
+@pytest.mark.parametrize("duo,grid", [(0, 5), (0, 300), (1, 7)], ids=["two_pages_per_wavefront", "one_page_per_wavefront", "two_wavefronts_per_page"])
+def test_sim_per_stream_status_names_the_damaged_streams(sim, duo, grid):
+    """Round 5: the batch status is one OR-ed word for up to 4 096 streams; every stream now has a status word of its
+    own (DcTable::status, read back by BrotligDecodeBatchStreamStatus).  64 streams, three damaged in three ways (refused when fetched,
+    refused at page end, refused by the prepare kernel): exactly those three are named, with the right bit, in every kernel form, and the
+    61 others are bit-exact."""
+    from fuzzcases import damaged_batch_for_stream_status
+    streams, sizes, datas, expect = damaged_batch_for_stream_status()
+    sim.sim_stream_status.restype = ctypes.c_uint32
+    sim.sim_stream_status.argtypes = [ctypes.c_uint32]
+    sim.sim_set_duo(duo)
+    try:
+        outs, status = run_batch(sim, streams, sizes, grid=grid)
+    finally:
+        sim.sim_set_duo(1 if os.environ.get("BROTLIG_SIM_DUO", "0") == "1" else 0)
+    assert status == 3
+    got = {i: sim.sim_stream_status(i) for i in range(len(streams))}
+    assert {i: v for i, v in got.items() if v} == expect
+    for i, d in enumerate(datas):
+        if d is not None:
+            assert np.array_equal(outs[i], d), i
+
+
+def test_sim_host_rule_exactly_one_kernel_decodes(sim):
+    """The host launches BOTH page kernels when the output size leaves the page count open, and the device decides (DecodeArgs::duo_limit
+    against the page count the prepare kernel found); it skips the policy kernel when no two pages can meet (csrc/brotlig_hip.hip enqueue()).
+    The same sequence on the simulator, with a small injected limit: page counts on both sides of it -- and AT it -- are decoded
+    by exactly one of the two kernels (the page counter moves under one of them only), bit-exact either way."""
+    for name in ("sim_counter_after_duo", "sim_counter_after_classic"):
+        getattr(sim, name).restype = ctypes.c_uint32
+    sim.sim_set_host_rule.argtypes = [ctypes.c_uint32]
+    d = D.mixed(9 * 65536 + 100, 31)                                 # 10 pages
+    stream = E.encode(d)
+    try:
+        for limit, grid, by_duo in ((10, 4, True), (9, 4, False), (11, 4, True), (10, 16, True), (3, 16, False)):
+            sim.sim_set_host_rule(limit)
+            outs, status = run_batch(sim, [stream], [len(d)], grid=grid)
+            assert status == 0 and np.array_equal(outs[0], d), (limit, grid)
+            duo_took, classic_took = sim.sim_counter_after_duo(), sim.sim_counter_after_classic()
+            assert (duo_took >= 10 and classic_took == 0) if by_duo else (duo_took == 0 and classic_took >= 10), (limit, grid, duo_took, classic_took)
+    finally:
+        sim.sim_set_host_rule(0)

@@ -1,4 +1,4 @@
-"""The split decode path (brotli_g_sdk_amd/csrc/experimental/brotlig_split_kernels.h) on the CPU simulator: the entropy kernel's command /
+"""The split decode path (profiles/experiments/split_path/brotlig_split_kernels.h) on the CPU simulator: the entropy kernel's command /
 literal arrays are assembled by a few lines of Python here and must give the encoder's input; the assembly kernel must give the
 same bytes from the same arrays (test further down)."""
 import ctypes
@@ -17,7 +17,7 @@ LIT_STRIDE = 131072 + 64
 
 @pytest.fixture(scope="module")
 def sim():
-    L = build_sim("libbrotlig_sim.so")
+    L = build_sim("libbrotlig_sim_split.so", split=True)
     L.sim_entropy_batch.restype = ctypes.c_int
     L.sim_entropy_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
