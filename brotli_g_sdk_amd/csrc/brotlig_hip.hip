@@ -37,10 +37,11 @@ static_assert(sizeof(BrotligStreamDesc) == sizeof(StreamDesc), "descriptor layou
     fprintf(stderr, "brotlig_hip: %s failed: %s\n", #expr, hipGetErrorString(_e)); return BROTLIG_ERROR_GENERIC; } } while (0)
 
 // Device workspace (the reference's `meta` buffer): word 0 status, word 1 page counter, word 2
-// preconditioned-stream count, word 3 pairing policy, words 8..39 scheduling buckets, words 64..
+// preconditioned-stream count, word 3 pairing policy, words 8..135 scheduling buckets, words 192..
 // page_base[num_streams + 1], then (1 KiB aligned) one DcTable per stream, then -- if the caller's
 // workspace has the room -- the page schedule (one word per page).
-constexpr size_t kWsHeaderWords = 64;
+constexpr size_t kWsHeaderWords = 192;
+static_assert(kWsHeaderWords >= kStatusWords, "the status words of the kernels (brotlig_kernels.h)");
 size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 1023u) & ~(size_t)1023u; }
 // per-half slots for the prefix-code symbols that overflow the LDS arrays, for every workgroup of the largest decode grid
 // (8192 workgroups x 2 halves x kFarSymStride uint16 = 30 MiB: the size brotlig_amd.h documents for the workspace)
@@ -692,7 +693,8 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
         hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, nullptr, a);
     }
     hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, nullptr, a);
-    hipLaunchKernelGGL(brotlig_decode_kernel_timed, dim3(g.decode), dim3(64), 0, nullptr, a);
+    if (BROTLIG_WAVE_TIMES) hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, nullptr, a);     // (diagnostics build: the product kernel with wave times)
+    else hipLaunchKernelGGL(brotlig_decode_kernel_timed, dim3(g.decode), dim3(64), 0, nullptr, a);
     HIP_OK(hipDeviceSynchronize());
     std::vector<unsigned long long> h(prof_words);
     HIP_OK(hipMemcpy(h.data(), prof.p, prof_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));

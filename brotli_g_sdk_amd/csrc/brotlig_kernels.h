@@ -78,7 +78,7 @@ struct DecodeArgs {
     uint32_t* page_base;    // [num_streams + 1] exclusive prefix of page counts
     uint32_t* work_counter; // [1] next global page index
     uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams, [3] pairing policy,
-                            // [8..23] pages per scheduling bucket, [24..39] bucket fill cursors
+                            // [8..8+B) pages per scheduling bucket, [8+B..8+2B) bucket fill cursors (B = kBuckets <= 64; kStatusWords in all)
     uint32_t* order;        // [order_cap] page schedule: global page indices grouped by bucket (null: page order)
     uint32_t  order_cap;
     uint32_t  duo_limit;    // batches of up to this many pages belong to brotlig_decode_duo_kernel (two wavefronts per page), larger ones to
@@ -1976,11 +1976,17 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
 // consumer polls it, reads the slot, and gives it back through `consumed` as soon as the group's literals are in the
 // window.
 constexpr uint32_t kDuoSlots = 4;
-enum : uint32_t { kDuoGroup = 1u, kDuoRound = 2u, kDuoPageStart = 4u, kDuoPageEnd = 8u, kDuoFinish = 16u, kDuoBad = 32u, kDuoDelta = 64u };
+// When the producer is this many steps ahead of the consumer (0 = never) it also does the group's dependency analysis -- which needs
+// positions only -- and sends the masks along: on copy-dense pages the consumer is the longer half (samples16: 64 % of the fused time).
+#ifndef BROTLIG_TUNE_DUO_DEPS_AHEAD
+#define BROTLIG_TUNE_DUO_DEPS_AHEAD 1     // round 5, timed on the device: one samples16 page 0.688 -> 0.655 ms, records 0.343 -> 0.335, runs 0.277 -> 0.270, text even
+#endif
+enum : uint32_t { kDuoGroup = 1u, kDuoRound = 2u, kDuoPageStart = 4u, kDuoPageEnd = 8u, kDuoFinish = 16u, kDuoBad = 32u, kDuoDelta = 64u, kDuoDeps = 128u };
 enum : uint32_t { kDuoOk = 1u << 31, kDuoCopies = 1u << 30 };         // flags above the distance (< 2^18)
 struct __attribute__((aligned(16))) DuoStep {
     uint32_t kind, round_bytes, litcount, f0;                           // what the step is; sizes of its round; first literal of its group
     uint32_t ins[32], tot[32], dist[32], rel0[32], lit_a[32];           // the round's commands (steps with kDuoRound)
+    uint32_t dep[32];                                                   // the group's dependency masks (steps with kDuoDeps)
     uint64_t lits[GeoSolo::kStageBytes / 8];                            // the group's literals, consumption order (or the PageJob of a page start)
 };
 static_assert(sizeof(PageJob) <= GeoSolo::kStageBytes, "a page start carries its job in the literal area");
@@ -1995,6 +2001,8 @@ struct __attribute__((aligned(16))) DuoLds {
     uint8_t  win[GeoSolo::kWin + 16] __attribute__((aligned(16)));
     DuoStep  step[kDuoSlots];
     uint32_t produced, consumed;                                        // steps handed over / given back so far
+    uint32_t p_start_bits[GeoSolo::kRoundMax / 32];                     // the producer's own piece bitmaps (kDuoDeps)
+    uint8_t  p_start_cum[GeoSolo::kRoundMax / 32];
     uint32_t len_code_tab[48];
 };
 
@@ -2086,7 +2094,21 @@ __device__ inline void duo_producer(DuoLds& D, const DecodeArgs& a)
                     // would read as the flags; a copy that is not valid is not made, as in decode_pages)
                     S.dist[sl] = (cp ? dist : 0u) | (ok_cmd ? kDuoOk : 0u) | (cp ? kDuoCopies : 0u);
                 }
-                if (lane == 0u) { S.kind = kDuoGroup | (g == 0u ? kDuoRound : 0u); S.round_bytes = round_bytes; S.litcount = litcount; S.f0 = F0; }
+                uint32_t with_deps = 0u;
+                if (BROTLIG_TUNE_DUO_DEPS_AHEAD != 0) {
+                    const uint32_t ahead = wave::bcast(k - wave::lds_load_acquire(&D.consumed), 0u);
+                    if (ahead >= (uint32_t)BROTLIG_TUNE_DUO_DEPS_AHEAD) {
+                        const uint32_t ca = cs > g0 ? cs : g0, cb = rel0 + tot < g1 ? rel0 + tot : g1;
+                        const uint32_t plen = (in_group && cp && cb > ca) ? cb - ca : 0u;
+                        const uint32_t pdst = out_pos + ca, psrc = pdst - (cp ? dist : 0u);
+                        const uint32_t src_end = psrc + min_u32(plen, dist);
+                        const uint32_t dep = piece_dependencies<PhaseClock<false>, G>(D.p_start_bits, D.p_start_cum, on, wave::ballot64(in_group), la - g0, out_pos + g0,
+                                                                                     psrc, src_end, plen != 0u, sl, clk);
+                        if (lane < 32u) S.dep[sl] = dep;
+                        with_deps = kDuoDeps;
+                    }
+                }
+                if (lane == 0u) { S.kind = kDuoGroup | (g == 0u ? kDuoRound : 0u) | with_deps; S.round_bytes = round_bytes; S.litcount = litcount; S.f0 = F0; }
                 uint8_t* const lits = reinterpret_cast<uint8_t*>(S.lits);
                 if (on) {
                     const uint32_t cf1 = F1 < prev_tail ? F1 : prev_tail;
@@ -2211,7 +2233,9 @@ __device__ inline void duo_consumer(DuoLds& D, const DecodeArgs& a)
             const FarSources far = fetch_far_sources(job.out, D.win, psrc - view.win_base, false, plen, psrc, far_len, sl);
             const bool far_direct = far.direct;
             const uint32_t stage_off = far.stage_off;
-            const uint32_t dep_mask = piece_dependencies<PhaseClock<false>, G>(D.start_bits, D.start_cum, on, wave::ballot64(in_group), (rel0 > g0 ? rel0 : g0) - g0, gpos,
+            uint32_t dep_mask;
+            if (BROTLIG_TUNE_DUO_DEPS_AHEAD != 0 && (wave::uniform(S->kind) & kDuoDeps) != 0u) dep_mask = lower ? S->dep[sl] : 0u;
+            else dep_mask = piece_dependencies<PhaseClock<false>, G>(D.start_bits, D.start_cum, on, wave::ballot64(in_group), (rel0 > g0 ? rel0 : g0) - g0, gpos,
                                                                               psrc, src_end, plen != 0u && !far_direct, sl, clk);
             // literal runs: from the step's queue to their place in the window; then the slot goes back to the producer
             {
@@ -2617,16 +2641,28 @@ __device__ inline void page_sizes(const DecodeArgs& a, uint32_t g, uint32_t tota
     in_size = i + 1u < np ? load_u32(table + 4u * (i + 1u)) - off : load_u32(table);
     out_size = (i + 1u == np && si.last_page_size) ? si.last_page_size : si.page_size;
 }
-constexpr uint32_t kBuckets = 16;
+// Round 5: the buckets are a quarter / an eighth of an octave wide instead of half an octave (BROTLIG_TUNE_BUCKETS_PER_OCTAVE).  On the mixed
+// benchmark the pairing policy below keeps the two halves of a wavefront in step (a free half waits for its neighbour), so what a pair costs
+// is its SLOWER page: the narrower the bucket, the closer two neighbours of the schedule are in compressed size -- the one cost signal a page
+// table holds.  (The data classes of the benchmark already sat in buckets of their own: text 3, samples16 4, records 6-9, runs 12-13 of 16.)
+#ifndef BROTLIG_TUNE_BUCKETS_PER_OCTAVE
+#define BROTLIG_TUNE_BUCKETS_PER_OCTAVE 8
+#endif
+constexpr uint32_t kBucketsPerOctave = BROTLIG_TUNE_BUCKETS_PER_OCTAVE;
+static_assert(kBucketsPerOctave == 2u || kBucketsPerOctave == 4u || kBucketsPerOctave == 8u, "half, quarter or eighth octaves");
+constexpr uint32_t kBuckets = 8u * kBucketsPerOctave;                   // 7.5 .. 7.9 octaves of compression ratio, then "denser", then "stored"
+constexpr uint32_t kBucketStep16 = kBucketsPerOctave == 2u ? 46341u : kBucketsPerOctave == 4u ? 55109u : 60097u;    // 2^(-1/n) in 16-bit fixed point
 __device__ __forceinline__ uint32_t page_bucket(uint32_t in_size, uint32_t out_size)
 {
     if (in_size >= out_size) return kBuckets - 1u;                      // stored (or nonsense): cheapest, last
-    // half-octave steps of out / in: bucket b holds in_size in (out / 2^((b+1)/2), out / 2^(b/2)]
-    uint32_t b = 0, t = (out_size * 181u) >> 8;                          // 181/256 ~ 1/sqrt(2); out_size <= 128 KiB
-    while (b < kBuckets - 2u && in_size <= t) { ++b; t = (t * 181u) >> 8; }
+    // bucket b holds in_size in (out / 2^((b+1)/n), out / 2^(b/n)]
+    uint32_t b = 0, t = (uint32_t)(((uint64_t)out_size * kBucketStep16) >> 16);     // out_size <= 128 KiB
+    while (b < kBuckets - 2u && in_size <= t) { ++b; t = (uint32_t)(((uint64_t)t * kBucketStep16) >> 16); }
     return b;
 }
 constexpr uint32_t kOrderHist = 8, kOrderCursor = 8 + kBuckets;         // status word offsets
+constexpr uint32_t kStatusWords = 8u + 2u * 64u;                        // the workspace header: room for the widest setting
+static_assert(kOrderCursor + kBuckets <= kStatusWords && kBuckets <= 64u, "status words; one lane per bucket in the order kernels");
 
 __global__ void __launch_bounds__(64) brotlig_order_count_kernel(DecodeArgs a)
 {
@@ -2646,11 +2682,17 @@ __global__ void __launch_bounds__(64) brotlig_order_count_kernel(DecodeArgs a)
 
 __global__ void __launch_bounds__(64) brotlig_order_scatter_kernel(DecodeArgs a)
 {
-    __shared__ uint32_t cnt[kBuckets], base[kBuckets];
+    __shared__ uint32_t cnt[kBuckets], base[kBuckets], start[kBuckets];
     const uint32_t lane = threadIdx.x, total = a.page_base[a.num_streams];
     if (a.order == nullptr || total > a.order_cap) return;
-    uint32_t start[kBuckets];
-    { uint32_t run = 0; for (uint32_t b = 0; b < kBuckets; ++b) { start[b] = run; run += a.status[kOrderHist + b]; } }
+    {   // where each bucket starts in the schedule: exclusive prefix of the histogram, one bucket per lane
+        const uint32_t h = lane < kBuckets ? a.status[kOrderHist + lane] : 0u;
+        const uint32_t incl_half = wave::half_scan_incl(h);
+        const uint32_t lower_total = wave::bcast(incl_half, 31u);
+        const uint32_t incl = lane < 32u ? incl_half : incl_half + lower_total;
+        if (lane < kBuckets) start[lane] = incl - h;
+    }
+    wave::sync();
     for (uint32_t g0 = blockIdx.x * 64u; g0 < total; g0 += gridDim.x * 64u) {      // uniform trip count
         const uint32_t g = g0 + lane;
         if (lane < kBuckets) cnt[lane] = 0u;
@@ -2665,11 +2707,7 @@ __global__ void __launch_bounds__(64) brotlig_order_scatter_kernel(DecodeArgs a)
         wave::sync();
         if (lane < kBuckets) base[lane] = cnt[lane] ? atomicAdd(a.status + kOrderCursor + lane, cnt[lane]) : 0u;
         wave::sync();
-        if (g < total) {
-            uint32_t s0 = 0;
-            for (uint32_t k = 0; k < kBuckets; ++k) s0 = k == b ? start[k] : s0;
-            a.order[s0 + base[b] + rank] = g;
-        }
+        if (g < total) a.order[start[b] + base[b] + rank] = g;
         wave::sync();
     }
 }
@@ -2703,6 +2741,11 @@ __global__ void __launch_bounds__(64) brotlig_policy_kernel(DecodeArgs a)
     }
 }
 
+// BROTLIG_WAVE_TIMES (diagnostics build, profiles/tools/wave_times.py): the PRODUCT kernel records the first and last 100 MHz tick of every
+// wavefront (two scalar clock reads and one store per wavefront); BrotligDecodePhaseProfile then launches it instead of the phase-timer twin.
+#ifndef BROTLIG_WAVE_TIMES
+#define BROTLIG_WAVE_TIMES 0
+#endif
 // Kernel 2: persistent waves; each half pulls pages until the counter runs out (decode_pages).
 template <bool kProf>
 __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
@@ -2724,10 +2767,11 @@ __device__ __forceinline__ void decode_kernel_body(const DecodeArgs& a)
                                                                     // page counter; all of them when the batch is the two-wavefront kernel's
     const uint32_t doubles = total0 > gridDim.x ? total0 - gridDim.x : 0u;     // wavefronts that need both halves
     unsigned long long t_begin = 0;
-    if constexpr (kProf) t_begin = wave::realtime();         // 100 MHz, the same counter on every compute unit
+    constexpr bool kTimes = kProf || BROTLIG_WAVE_TIMES;
+    if constexpr (kTimes) t_begin = wave::realtime();         // 100 MHz, the same counter on every compute unit
     if (blockIdx.x >= doubles) decode_pages<kProf, true>(W, a, prof_lds);
     else decode_pages<kProf, false>(W, a, prof_lds);
-    if constexpr (kProf) {      // when each wavefront came and went (round 5: how long the launch's tail is -- profiles/tools/wave_times.py)
+    if constexpr (kTimes) {     // when each wavefront came and went (round 5: how long the launch's tail is -- profiles/tools/wave_times.py)
         if (lane == 0u && a.prof != nullptr) {
             a.prof[kNumPhases + 2u * blockIdx.x] = t_begin;
             a.prof[kNumPhases + 2u * blockIdx.x + 1u] = wave::realtime();

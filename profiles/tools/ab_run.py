@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--dir", default=os.path.join(ROOT, "build", "abv"))
     ap.add_argument("--out", default=None)
     ap.add_argument("--encoder-flags", type=int, default=0)
+    ap.add_argument("--distinct", type=int, default=256, help="distinct encoded pages per stream (4096 = no tiling at all)")
     a = ap.parse_args()
     import torch
     import bench
@@ -28,7 +29,7 @@ def main():
     names = [os.path.basename(p)[4:-3] for p in libs]
     results = {}
     for w in a.workloads:
-        streams, expected = bench.build_streams(w, list(range(256 if w == "bc3" else 16)), 256 if w == "bc3" else 4096, 8 if w == "bc3" else 256)
+        streams, expected = bench.build_streams(w, list(range(256 if w == "bc3" else 16)), 256 if w == "bc3" else 4096, 8 if w == "bc3" else a.distinct)
         out_sizes = [len(e) for e in expected] if w == "bc3" else None
         per = {n: [] for n in names}
         rest = {}

@@ -22,6 +22,7 @@ static struct {
     uint64_t simple_groups, simple_groups_long; /* groups whose copy pieces are all direct-eligible (<=32 bytes / any length) */
     uint64_t ingroup_pieces, long_pieces;
     uint64_t levels_fwd, fwd_pieces, p2_pieces;   /* with periodic forwarding (see below) */
+    uint64_t levels_copyonly, false_dep_pieces;   /* round 5: dependencies counted only on the COPY bytes of earlier commands (their literal bytes are in the window before the levels start) */
 } S;
 static __thread uint32_t t_win_base, t_page_out;
 static int bucket(uint32_t v) { return v == 0 ? 0 : v < 2 ? 1 : v < 4 ? 2 : v < 8 ? 3 : v < 16 ? 4 : v < 32 ? 5 : v < 128 ? 6 : 7; }
@@ -50,10 +51,11 @@ static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_po
         __sync_fetch_and_add(&S.groups, 1);
         /* pieces */
         uint32_t lvl[32], plen[32], first = 32;
+        uint32_t lvc[32];
         uint32_t lvf[32], p2[32], cdst[32];     /* model: a piece with a period of 1, 2 or 4 bytes whose pattern lies inside ONE earlier such piece takes its word from that piece's word (no wait) */
         int any = 0, not_simple = 0, not_simple_long = 0;
         for (uint32_t k = 0; k < n; ++k) {
-            lvl[k] = 0; plen[k] = 0; lvf[k] = 0; p2[k] = 0; cdst[k] = 0;
+            lvl[k] = 0; plen[k] = 0; lvf[k] = 0; p2[k] = 0; cdst[k] = 0; lvc[k] = 0;
             uint32_t r0 = rel0[k], t = q[k].insert_len + q[k].copy_len, cs = r0 + q[k].insert_len;
             if (!(r0 < g1 && r0 + t > g0)) continue;
             if (first == 32) first = k;
@@ -85,6 +87,17 @@ static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_po
                 }
             }
             lvl[k] = l; any = 1;
+            {   /* the same with the literal bytes of earlier commands taken as final */
+                uint32_t lc = 1;
+                if (src_end > gpos)
+                    for (uint32_t j = first; j < k; ++j) {
+                        if (!plen[j]) continue;
+                        uint32_t cj = out_pos + (rel0[j] + q[j].insert_len > g0 ? rel0[j] + q[j].insert_len : g0), bj = out_pos + (rel0[j + 1] < g1 ? rel0[j + 1] : g1);
+                        if (cj < src_end && bj > psrc && lvc[j] + 1 > lc) lc = lvc[j] + 1;
+                    }
+                lvc[k] = lc;
+                if (lc < l) __sync_fetch_and_add(&S.false_dep_pieces, 1);
+            }
             {   /* forwarding model */
                 uint32_t d = q[k].dist, lf = 1; int fwd = 0;
                 p2[k] = (d == 1 || d == 2 || d == 4) && d < pl && far_len == 0; cdst[k] = pdst;
@@ -105,6 +118,7 @@ static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_po
         uint32_t maxl = 0;
         for (uint32_t k = 0; k < n; ++k) if (lvl[k] > maxl) maxl = lvl[k];
         __sync_fetch_and_add(&S.levels, maxl);
+        { uint32_t mc = 0; for (uint32_t k = 0; k < n; ++k) if (lvc[k] > mc) mc = lvc[k]; __sync_fetch_and_add(&S.levels_copyonly, mc); }
         { uint32_t mf = 0; for (uint32_t k = 0; k < n; ++k) if (lvf[k] > mf) mf = lvf[k]; __sync_fetch_and_add(&S.levels_fwd, mf); }
         __sync_fetch_and_add(&S.level_hist[maxl < 39 ? maxl : 39], 1);
         for (uint32_t l = 1; l <= maxl; ++l) {
@@ -137,13 +151,13 @@ int main(int argc, char** argv)
         printf("{\"file\": \"%s\", \"rc\": %d, \"ratio\": %.3f, \"pages\": %.0f, \"rounds_per_page\": %.1f, \"cmds_per_round\": %.2f, \"bytes_per_cmd\": %.2f, "
                "\"lit_frac\": %.3f, \"lits_per_round\": %.1f, \"groups_per_round\": %.3f, \"slides_per_round\": %.3f, \"levels_per_group\": %.3f, "
                "\"copy_pieces_per_group\": %.2f, \"far_direct\": %.3f, \"far_staged\": %.3f, \"far_staged_l1\": %.3f, \"near_nodep\": %.3f, \"near_dep\": %.3f, "
-               "\"simple_groups\": %.3f, \"simple_groups_anylen\": %.3f, \"ingroup_src_pieces_per_group\": %.2f, \"long_below_pieces_per_group\": %.2f, \"short_lt8\": %.3f, \"overlap_lt32\": %.3f, \"ready_per_level\": %.2f, \"team_level_frac\": %.3f, \"maxlen_per_level\": %.1f, \"lit_pieces_per_group\": %.2f, \"levels_per_group_with_periodic_forwarding\": %.3f, \"period_1_2_4_pieces\": %.3f, \"forwarded\": %.3f,\n",
+               "\"simple_groups\": %.3f, \"simple_groups_anylen\": %.3f, \"ingroup_src_pieces_per_group\": %.2f, \"long_below_pieces_per_group\": %.2f, \"short_lt8\": %.3f, \"overlap_lt32\": %.3f, \"ready_per_level\": %.2f, \"team_level_frac\": %.3f, \"maxlen_per_level\": %.1f, \"lit_pieces_per_group\": %.2f, \"levels_per_group_with_periodic_forwarding\": %.3f, \"period_1_2_4_pieces\": %.3f, \"forwarded\": %.3f, \"levels_per_group_copy_bytes_only\": %.3f, \"pieces_with_a_literal_only_dependency\": %.3f,\n",
                argv[i], rc, (double)osz / sz, pages, R / pages, (double)S.cmds / R, (double)osz / S.cmds, (double)S.lit_bytes / osz, (double)S.lit_bytes / R,
                G / R, (double)S.slides / R, (double)S.levels / G, (double)S.pieces_copy / G,
                (double)S.far_direct / S.pieces_copy, (double)S.far_staged / S.pieces_copy, (double)S.ring_like / S.pieces_copy, (double)S.near_nodep / S.pieces_copy, (double)S.near_dep / S.pieces_copy,
                S.simple_groups / G, S.simple_groups_long / G, S.ingroup_pieces / G, S.long_pieces / G,
                (double)S.short_pieces / S.pieces_copy, (double)S.overlap_pieces / S.pieces_copy, (double)S.ready_pieces / (S.levels ? S.levels : 1),
-               (double)S.team_levels / (S.levels ? S.levels : 1), (double)S.lvl_bytes / (S.levels ? S.levels : 1), (double)S.lit_pieces / G, (double)S.levels_fwd / G, (double)S.p2_pieces / S.pieces_copy, (double)S.fwd_pieces / S.pieces_copy);
+               (double)S.team_levels / (S.levels ? S.levels : 1), (double)S.lvl_bytes / (S.levels ? S.levels : 1), (double)S.lit_pieces / G, (double)S.levels_fwd / G, (double)S.p2_pieces / S.pieces_copy, (double)S.fwd_pieces / S.pieces_copy, (double)S.levels_copyonly / G, (double)S.false_dep_pieces / S.pieces_copy);
         printf(" \"level_hist\": [");
         for (int l = 0; l < 12; ++l) printf("%s%.3f", l ? ", " : "", S.level_hist[l] / G);
         printf("], \"ins_hist(0,1,2-3,4-7,8-15,16-31,32-127,128+)\": [");

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Small-batch behaviour: kernel time of 1, 8, 64, 512 and 4096 pages (config 2 data and mixed data)."""
+import os as _os; _os.environ.setdefault("BROTLIG_ENABLE_DEBUG_KNOBS", "1")    # the kernel-selection switches are inert without it (diagnostics only)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Latency of ONE 64 KiB page per data class (the small-batch regime: one page per wavefront, whole SIMD to itself), with the
 phase shares of that launch: which classes decide the 512-page / config-2 numbers, and where their time goes."""
+import os as _os; _os.environ.setdefault("BROTLIG_ENABLE_DEBUG_KNOBS", "1")    # the kernel-selection switches are inert without it (diagnostics only)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from brotli_g_sdk_amd import api, datagen as D, encoder as E

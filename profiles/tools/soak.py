@@ -3,6 +3,7 @@
 pre-conditioned streams against the bytes they were encoded from, damaged streams next to valid ones).
   python profiles/tools/soak.py [first_seed] [n_plain] [n_precon] [n_corrupt] [mode]
 mode: 0 = the kernel the batch size selects (these batches: two wavefronts per page), 1 = one wavefront per one or two pages, 2 = two wavefronts per page."""
+import os as _os; _os.environ.setdefault("BROTLIG_ENABLE_DEBUG_KNOBS", "1")    # the kernel-selection switches are inert without it (diagnostics only)
 import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -48,6 +48,7 @@ alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 j = {
     "kernel": "brotlig_decode_kernel", "build": label, "workload": bench["config"]["workload"],
     "kernel_source_sha16": bench["roofline"].get("kernel_source_sha16"),
+    "kernel_disasm_sha16": bench["roofline"].get("kernel_disasm_sha16"),     # what bench.py gates the reuse of this measurement on
     "launches_averaged": {"FETCH_SIZE": nf, "WRITE_SIZE": nw},
     "FETCH_SIZE_KiB_per_launch": fetch, "WRITE_SIZE_KiB_per_launch": write,
     "fetch_bytes_per_launch": fetch * 1024, "write_bytes_per_launch": write * 1024,

@@ -50,7 +50,7 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     }
     std::vector<uint32_t> page_base(num_streams + 1, 0);
     uint32_t counter = 0;
-    uint32_t status_words[64] = {0};
+    uint32_t status_words[kStatusWords] = {0};
     std::vector<DcTable> dc(num_streams);
     DecodeArgs a{};
     a.in = in; a.in_bytes = in_bytes; a.out = out; a.out_bytes = out_bytes; a.scratch = scratch;
@@ -110,7 +110,7 @@ extern "C" int sim_entropy_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* 
     }
     std::vector<uint32_t> page_base(num_streams + 1, 0);
     uint32_t counter = 0, counter2 = 0;
-    uint32_t status_words[64] = {0};
+    uint32_t status_words[kStatusWords] = {0};
     std::vector<DcTable> dc(num_streams);
     DecodeArgs a{};
     a.in = in; a.in_bytes = in_bytes; a.out = out; a.out_bytes = out_bytes; a.scratch = g_scratch;
