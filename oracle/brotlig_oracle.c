@@ -387,6 +387,7 @@ static void delta_decode(const DcParams* dc, size_t page_start, size_t page_end,
 typedef struct { uint32_t insert_len, copy_len, dist; } Cmd;
 #ifdef BROTLIG_ORACLE_TRACE
 static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_pos, uint32_t litcount, uint32_t rlit);
+static void brotlig_oracle_trace_literal(uint32_t j, uint32_t code_len);    /* literal j of the round (sub-stream j mod 32) and the length of its code */
 #endif
 
 /* PageDecoder.cpp:65-268.  `in` is the SafeBuf of the whole compressed input,
@@ -499,6 +500,9 @@ static int pd_run(PageDecoder* pd, const SafeBuf* in, size_t in_size, size_t in_
 
             for (uint32_t j = 0; j < rlit; ++j) {                                   /* :202-206 */
                 uint32_t bits = g_rev15[ds_peek(&ds, 15)];                          /* DecodeLiteral, :322-327 */
+#ifdef BROTLIG_ORACLE_TRACE
+                brotlig_oracle_trace_literal(j, pd->codelens[2][bits]);
+#endif
                 ds_consume(&ds, pd->codelens[2][bits]);
                 if (lq_back < lq_end) *lq_back++ = (uint8_t)pd->symbols[2][bits];
                 ds_switch(&ds);

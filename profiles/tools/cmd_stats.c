@@ -25,6 +25,21 @@ static struct {
     uint64_t levels_copyonly, false_dep_pieces;   /* round 5: dependencies counted only on the COPY bytes of earlier commands (their literal bytes are in the window before the levels start) */
 } S;
 static __thread uint32_t t_win_base, t_page_out;
+/* round 5 ("two literals per LUT lookup"): how often do two consecutive literals of ONE sub-stream (j and j + 32 of a
+ * round: what the kernel's literal loop decodes back to back) fit a table index of 8 / 10 / 12 bits together? */
+static struct { uint64_t lits, pairs, fit8, fit10, fit12, len_sum, len_hist[16]; } LP;
+static __thread uint32_t t_lane_len[32];
+static void brotlig_oracle_trace_literal(uint32_t j, uint32_t len)
+{
+    __sync_fetch_and_add(&LP.lits, 1); __sync_fetch_and_add(&LP.len_sum, len); __sync_fetch_and_add(&LP.len_hist[len & 15], 1);
+    if (j >= 32u && ((j >> 5) & 1u)) {          /* second literal of a pair of its lane: (0,32), (64,96), ... */
+        uint32_t sum = t_lane_len[j & 31u] + len;
+        __sync_fetch_and_add(&LP.pairs, 1);
+        if (sum <= 8) __sync_fetch_and_add(&LP.fit8, 1);
+        if (sum <= 10) __sync_fetch_and_add(&LP.fit10, 1);
+        if (sum <= 12) __sync_fetch_and_add(&LP.fit12, 1);
+    } else t_lane_len[j & 31u] = len;
+}
 static int bucket(uint32_t v) { return v == 0 ? 0 : v < 2 ? 1 : v < 4 ? 2 : v < 8 ? 3 : v < 16 ? 4 : v < 32 ? 5 : v < 128 ? 6 : 7; }
 static int dbucket(uint32_t d) { return d < 8 ? 0 : d < 32 ? 1 : d < 128 ? 2 : d < 528 ? 3 : d < 2048 ? 4 : d < 8192 ? 5 : d < 32768 ? 6 : 7; }
 
@@ -144,7 +159,7 @@ int main(int argc, char** argv)
         fclose(f);
         uint32_t osz = DecompressedSize(in);
         uint8_t* out = malloc((size_t)osz + 64);
-        memset(&S, 0, sizeof S);
+        memset(&S, 0, sizeof S); memset(&LP, 0, sizeof LP);
         int used = 0;
         int rc = brotlig_oracle_decode((uint32_t)sz, in, &osz, out, 1, &used);
         double pages = osz / 65536.0, R = (double)S.rounds, G = (double)S.groups;
@@ -158,6 +173,9 @@ int main(int argc, char** argv)
                S.simple_groups / G, S.simple_groups_long / G, S.ingroup_pieces / G, S.long_pieces / G,
                (double)S.short_pieces / S.pieces_copy, (double)S.overlap_pieces / S.pieces_copy, (double)S.ready_pieces / (S.levels ? S.levels : 1),
                (double)S.team_levels / (S.levels ? S.levels : 1), (double)S.lvl_bytes / (S.levels ? S.levels : 1), (double)S.lit_pieces / G, (double)S.levels_fwd / G, (double)S.p2_pieces / S.pieces_copy, (double)S.fwd_pieces / S.pieces_copy, (double)S.levels_copyonly / G, (double)S.false_dep_pieces / S.pieces_copy);
+        printf(" \"literal_pairs\": {\"literals\": %llu, \"mean_code_bits\": %.2f, \"pairs_fitting_8_bits\": %.3f, \"10_bits\": %.3f, \"12_bits\": %.3f},\n",
+               (unsigned long long)LP.lits, LP.lits ? (double)LP.len_sum / LP.lits : 0.0, LP.pairs ? (double)LP.fit8 / LP.pairs : 0.0,
+               LP.pairs ? (double)LP.fit10 / LP.pairs : 0.0, LP.pairs ? (double)LP.fit12 / LP.pairs : 0.0);
         printf(" \"level_hist\": [");
         for (int l = 0; l < 12; ++l) printf("%s%.3f", l ? ", " : "", S.level_hist[l] / G);
         printf("], \"ins_hist(0,1,2-3,4-7,8-15,16-31,32-127,128+)\": [");

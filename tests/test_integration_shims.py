@@ -96,7 +96,7 @@ def test_multi_device_example_runs(built):
         test_multi_device_example_compiles_against_the_c_abi(built)
     r = subprocess.run([exe, "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "bit-exact" in r.stdout
+    assert "bit-exact" in r.stdout and "named as the damaged one" in r.stdout
 
 
 def test_decode_cpu_feedback_trampoline_of_the_integration_guide_runs(built):

@@ -120,5 +120,26 @@ int main(int argc, char** argv)
     }
     printf("%u streams over %u shards on %d device(s): %llu bytes bit-exact, slowest shard kernel %.3f ms, wall %.3f ms for 3 passes\n",
            (unsigned)N_STREAMS, live, devices, (unsigned long long)total, kernel_ms, wall_ms);
+
+    /* 5. which asset was damaged: break the magic byte of the second stream of the first shard on the device, decode that shard again,
+     *    and ask for one result per stream (BrotligDecodeBatchStreamStatus, round 5) -- the batch answer alone would not say which */
+    if (run[0].num_streams >= 2u) {
+        CHECK_HIP(hipSetDevice(run[0].device));
+        const uint32_t victim = 1u, i = first[run_of[0]] + victim;
+        uint64_t at = 0;
+        for (uint32_t k = 0; k < victim; ++k) at += (enc_size[first[run_of[0]] + k] + 15u) & ~(uint64_t)15u;
+        const uint8_t broken = (uint8_t)(enc[i][1] ^ 0x10);
+        CHECK_HIP(hipMemcpy((uint8_t*)run[0].d_in + at + 1u, &broken, 1, hipMemcpyHostToDevice));
+        if (BrotligDecodeBatchDevice(run[0].d_in, run[0].in_bytes, run[0].d_out, run[0].out_bytes, run[0].d_streams, run[0].num_streams,
+                                     run[0].d_workspace, (size_t)run[0].workspace_bytes, NULL, run[0].hip_stream) != BROTLIG_OK) return 1;
+        int32_t per_stream[N_STREAMS];
+        const BROTLIG_ERROR all = BrotligDecodeBatchStreamStatus(run[0].d_workspace, run[0].num_streams, per_stream, run[0].hip_stream);
+        if (all != BROTLIG_ERROR_CORRUPT_STREAM) { fprintf(stderr, "batch status %d, expected CORRUPT_STREAM\n", (int)all); return 1; }
+        for (uint32_t k = 0; k < run[0].num_streams; ++k)
+            if (per_stream[k] != (k == victim ? (int32_t)BROTLIG_ERROR_CORRUPT_STREAM : (int32_t)BROTLIG_OK)) {
+                fprintf(stderr, "stream %u of shard 0 reports %d\n", k, (int)per_stream[k]); return 1;
+            }
+        printf("per-stream status: stream %u of shard 0 named as the damaged one, the other %u are fine\n", victim, run[0].num_streams - 1u);
+    }
     return 0;
 }
