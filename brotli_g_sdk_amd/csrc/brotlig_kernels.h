@@ -152,7 +152,10 @@ template <> struct PhaseClock<true> {
 #define BROTLIG_ABLATE 0
 #endif
 enum : uint32_t { kAblLevels = 1u, kAblTeams = 2u, kAblOverlap = 4u, kAblFar = 8u, kAblSlide = 16u, kAblDeps = 32u, kAblLitStore = 64u,
-                  kAblOwnLane = 128u };
+                  kAblOwnLane = 128u, kAblRounds = 256u /* page starts only: job fetch, bit readers, the three table builds -- no round at all */,
+                  // parts of the table build left out (with kAblRounds: what each costs): the primary LUT, the canonical build (counts, scans,
+                  // symbols in code order), the RLE pass over the code lengths, the code-length code
+                  kAblTabLut = 512u, kAblTabCanon = 1024u, kAblTabRle = 2048u, kAblTabCl = 4096u };
 constexpr uint32_t kAblate = BROTLIG_ABLATE;
 
 // ---- tunables ---------------------------------------------------------------------------
@@ -554,6 +557,21 @@ __device__ __forceinline__ uint32_t advance_mod(uint32_t r, uint32_t step, uint3
     return r;
 }
 
+// Lanes (0..17) of a half whose code-length symbol (kCodeLenOrder) is smaller than lane sl's: the ties of the canonical order.
+__device__ __forceinline__ uint32_t cl_smaller_lanes(uint32_t sl)
+{
+    constexpr uint8_t order[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};      // = kCodeLenOrder
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 18u; ++k) {
+        uint32_t mk = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 18u; ++j) mk |= (order[j] < order[k] ? 1u : 0u) << j;
+        m = sl == k ? mk : m;
+    }
+    return m;
+}
+
 // One prefix-code table: which LDS arrays it lives in.
 struct TableRef {
     uint16_t* lut; uint32_t* sorted; uint16_t* limit; uint32_t* first_offs;
@@ -681,31 +699,44 @@ __device__ inline bool build_table(const TableRef& t, uint8_t* codelens, Reader&
         const uint32_t cl_sym = sl < 18u ? kCodeLenOrder[sl] : 31u;
         if (is_complex && sl < ncl) cl_len = br.read(5);
         if (cl_len > 9u) cl_len = 0u;                              // > 9 is invalid (2^9 table in the reference)
-        // canonical code of my code-length symbol: sum over symbols that precede it in (length, symbol) order
+        // canonical code of my code-length symbol: the symbols that precede it in (length, symbol) order each take 2^(my length - theirs) of
+        // its code space.  Round 5: counted from nine ballots (which lanes hold a code of length l?) -- the shorter ones by popcount, the
+        // ones of my own length by popcount under "lanes whose symbol is smaller than mine" (the symbol order is fixed: kCodeLenOrder) --
+        // instead of eighteen broadcasts of every lane's (length, symbol) to every lane.
         uint32_t cl_code = 0;
-        for (uint32_t j = 0; j < 18u; ++j) {
-            const uint32_t lj = wave::half_bcast(cl_len, j), sj = wave::half_bcast(cl_sym, j);
-            if (cl_len && lj && (lj < cl_len || (lj == cl_len && sj < cl_sym))) cl_code += 1u << (cl_len - lj);
+        if (!(kAblate & kAblTabCl)) {
+            const uint32_t smaller = cl_smaller_lanes(sl);
+#pragma unroll
+            for (uint32_t l = 1; l <= 9u; ++l) {
+                const uint32_t m = wave::half_of(wave::ballot_eq(cl_len, l));
+                if (l < cl_len) cl_code += (uint32_t)__popc(m) << (cl_len - l);
+                else if (l == cl_len) cl_code += (uint32_t)__popc(m & smaller);
+            }
         }
-        // 9-bit LUT: entry = sym << 4 | len, index = next 9 stream bits (LSB-first)
-        if (is_complex) for (uint32_t e = sl; e < 512u; e += 32u) scratch16[e] = 0;
+        // LUT over the next `tb` stream bits (LSB-first), tb = the longest code-length code of the page (<= 9; typically 4 .. 6): entry =
+        // sym << 4 | len.  (Rounds 1-4 always built the reference's 2^9 table: a lane with a 1- or 2-bit code wrote 256 or 128 entries.)
+        const uint32_t cl_longest = wave::half_max(cl_len);
+        const uint32_t tb = cl_longest > 0u ? cl_longest : 1u;
+        if (is_complex) for (uint32_t e = sl; e < (1u << tb); e += 32u) scratch16[e] = 0;
         wave::sync();
         {
-            const uint32_t reps = (is_complex && sl < 18u && cl_len) ? (1u << (9u - cl_len)) : 0u;
+            const uint32_t reps = (is_complex && sl < 18u && cl_len) ? (1u << (tb - cl_len)) : 0u;
             const uint32_t rcode = cl_len ? (__brev(cl_code) >> (32u - cl_len)) : 0u;
             for (uint32_t m = 0; m < reps; ++m) scratch16[rcode + (m << cl_len)] = (uint16_t)((cl_sym << 4) | cl_len);
         }
+        // the code lengths start out as zeros: the RLE pass below only stores the non-zero ones (most of an alphabet is unused)
+        if (is_complex) for (uint32_t o = 16u * sl; o < ((A + 15u) & ~15u); o += 512u) store16(codelens + o, Bytes16{0u, 0u, 0u, 0u});
         wave::sync();
 
         // RLE symbols: one (plus its extra bits) per sub-stream, round-robin, until A lengths exist
-        uint32_t produced = is_complex ? 0u : A;
+        uint32_t produced = (is_complex && !(kAblate & kAblTabRle)) ? 0u : A;
         uint32_t prev_len = 8;                                     // BROTLI_INITIAL_REPEATED_CODE_LENGTH
         while (wave::any(produced < A)) {
             const bool act = produced < A;
             uint32_t sym = 0, clen = 0, run = 0, extra = 0, nextra = 0;
             if (act) {
-                br.ensure(16);                                     // 9-bit code + up to 3 extra bits
-                const uint32_t e = scratch16[br.peek(9)];
+                br.ensure(16);                                     // <= 9-bit code + up to 3 extra bits
+                const uint32_t e = scratch16[br.peek(tb)];
                 sym = e >> 4; clen = e & 15u;
                 nextra = sym == 16u ? 2u : (sym == 17u ? 3u : 0u);
                 extra = ((uint32_t)(br.buf >> clen)) & ((1u << nextra) - 1u);
@@ -722,17 +753,20 @@ __device__ inline bool build_table(const TableRef& t, uint8_t* codelens, Reader&
             uint32_t value = sym;                                  // literal length
             if (sym == 17u) value = 0u;
             else if (sym == 16u) value = before ? from_lane : prev_len;    // repeat previous *literal* length
-            if (valid) {
+            if (valid && value != 0u) {                             // (zeros are there already)
                 const uint32_t end = min_u32(start + run, A);
                 for (uint32_t s = start; s < end; ++s) codelens[s] = (uint8_t)value;
             }
-            produced = min_u32(A, produced + wave::half_sum(valid ? run : 0u));
+            // (the valid lanes are a prefix of the half, and when a lane is not valid the lengths are complete: the sum over the valid lanes
+            // and the sum over all lanes give the same `produced` after the clamp -- one broadcast instead of a second scan)
+            produced = min_u32(A, produced + wave::half_bcast(incl, 31u));
             if (lit_mask) prev_len = last_lit;
         }
         wave::sync();
 
         // canonical build.  Each lane owns a contiguous block of symbols; per-(length, lane)
         // counters give every symbol its rank without atomics.
+        if (!(kAblate & kAblTabCanon)) {
         uint16_t* cnt = scratch16;                                 // [16][32]
         const uint32_t blk = (A + 31u) / 32u;
         const uint32_t b0 = sl * blk, b1 = min_u32(A, b0 + blk);
@@ -763,38 +797,45 @@ __device__ inline bool build_table(const TableRef& t, uint8_t* codelens, Reader&
             }
         // symbols beyond the LDS arrays went to global memory: stores first, then the reads below and in the rounds
         // (same CU, same L1: workgroup scope is enough)
+        }
         if (A != kLitAlphabet) wave::global_fence(); else wave::sync();
-        // primary LUT, one entry per lane per step
-        if (is_complex) {
-            uint32_t lim[8];                                       // limits of lengths 0..15, two per word
-            __builtin_memcpy(lim, t.limit, 32);
-            // length of the code whose left-justified 15-bit value range contains v (16: none)
-            auto length_of = [&lim](uint32_t v) {
-                uint32_t l = 1;
-#pragma unroll
-                for (int k = 1; k < 16; ++k) {
-                    const uint32_t w = lim[k >> 1];
-                    l += v >= ((k & 1) ? (w >> 16) : (w & 0xFFFFu)) ? 1u : 0u;
-                }
-                return l;
+        // primary LUT.  Round 5: filled in CODE order -- lane sl owns the lut_size / 32 consecutive code prefixes from (lut_size / 32) * sl on,
+        // entry index = the prefix bit-reversed.  The length of a code is monotone in its left-justified value (the limits are: each is the
+        // previous one plus the codes of its length, clamped), so only a lane's first prefix takes the search over all fifteen limits; from one
+        // prefix to the next the length is walked up against limit[l].  (Rounds 1-4: index order, two fifteen-compare searches per entry.)
+        if (is_complex && !(kAblate & kAblTabLut)) {
+            // length of the code whose left-justified 15-bit value range contains v (16: none): the limits are monotone, so a binary search
+            // over limit[1..15] (four reads) finds the first one above v
+            auto length_of = [&t](uint32_t v) {
+                uint32_t l = 0;                                     // invariant: limit[l] <= v (limit[0] taken as 0), answer in (l, l + span]
+                l += v >= (uint32_t)t.limit[l + 8u] ? 8u : 0u;
+                l += v >= (uint32_t)t.limit[l + 4u] ? 4u : 0u;
+                l += v >= (uint32_t)t.limit[l + 2u] ? 2u : 0u;
+                l += v >= (uint32_t)t.limit[l + 1u] ? 1u : 0u;
+                return l + 1u;
             };
-            for (uint32_t e = sl; e < lut_size; e += 32u) {
-                const uint32_t v = __brev(e) >> 17;                // LUT index bits as a left-justified 15-bit code prefix
-                const uint32_t l = length_of(v);
+            const uint32_t lut_bits = (uint32_t)t.lut_bits, per = lut_size >> 5, step = 1u << (15u - lut_bits);
+            uint32_t v = (per * sl) << (15u - lut_bits);           // left-justified 15-bit value of my first prefix
+            uint32_t l = length_of(v);
+            uint32_t lim_l = l <= 15u ? (uint32_t)t.limit[l] : 0xFFFFFFFFu;
+            uint32_t fo = l <= 15u ? t.first_offs[l] : 0u;
+            for (uint32_t i = 0; i < per; ++i, v += step) {
+                if (v >= lim_l) {
+                    do { ++l; lim_l = l <= 15u ? (uint32_t)t.limit[l] : 0xFFFFFFFFu; } while (v >= lim_l);
+                    fo = l <= 15u ? t.first_offs[l] : 0u;
+                }
                 uint32_t entry = kLongCode;
                 if (l <= 15u) {
-                    const uint32_t fo = t.first_offs[l];
                     const uint32_t idx = (fo >> 16) + ((v - (fo & 0xFFFFu)) >> (15u - l));
-                    if (l <= (uint32_t)t.lut_bits) {
+                    if (l <= lut_bits) {
                         entry = (table_sym(t, min_u32(idx, A - 1u)) << 4) | l;
-                    } else if (length_of(v + (1u << (15u - (uint32_t)t.lut_bits)) - 1u) == l &&
-                               idx + (1u << (l - (uint32_t)t.lut_bits)) <= A) {
+                    } else if (v + step - 1u < lim_l && idx + (1u << (l - lut_bits)) <= A) {
                         // every code under this prefix has length l: they are consecutive in code order, so the
                         // symbol is sorted[idx + the next l - lut_bits code bits] -- no length search at decode time
                         entry = kLutSubtree | (idx << 4) | l;
                     }
                 }
-                t.lut[e] = (uint16_t)entry;
+                t.lut[__brev(per * sl + i) >> (32u - lut_bits)] = (uint16_t)entry;
             }
         }
     }
@@ -1461,11 +1502,21 @@ __device__ __forceinline__ bool start_pages(const DecodeArgs& a, Lds& L, PageJob
         if (got) on_pull(job);
         const bool fresh = got && job.valid;
         const bool stored = fresh && job.in_size == job.out_size;
-        if (stored) {                                       // plain copy, 4 bytes per lane per step
-            const uint32_t words = job.out_size >> 2;
-            for (uint32_t i = sl; i < words; i += 32u)
-                reinterpret_cast<uint32_t*>(job.out)[i] = load_u32(job.in + 4u * i);
-            for (uint32_t i = (words << 2) + sl; i < job.out_size; i += 32u) job.out[i] = job.in[i];
+        if (stored) {                                       // plain copy: 16 bytes per lane, four loads in flight per step (round 5; 4 bytes per step
+                                                            // until then -- 0.06 ms for a page whose neighbour half waits for it)
+            const uint32_t vecs = job.out_size >> 4;        // (the page's output is 16-byte aligned; its input lies where the page table says)
+            for (uint32_t i = sl; i < vecs; i += 128u) {
+                Bytes16 v0, v1, v2, v3;
+                __builtin_memcpy(&v0, job.in + 16u * i, 16);
+                if (i + 32u < vecs) __builtin_memcpy(&v1, job.in + 16u * (i + 32u), 16);
+                if (i + 64u < vecs) __builtin_memcpy(&v2, job.in + 16u * (i + 64u), 16);
+                if (i + 96u < vecs) __builtin_memcpy(&v3, job.in + 16u * (i + 96u), 16);
+                store16(job.out + 16u * i, v0);
+                if (i + 32u < vecs) store16(job.out + 16u * (i + 32u), v1);
+                if (i + 64u < vecs) store16(job.out + 16u * (i + 64u), v2);
+                if (i + 96u < vecs) store16(job.out + 16u * (i + 96u), v3);
+            }
+            for (uint32_t i = (vecs << 4) + sl; i < job.out_size; i += 32u) job.out[i] = job.in[i];
         }
         if (fresh && !stored) { start = true; need = false; }
     }
@@ -1719,10 +1770,12 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
                     // an undefined code description rejects the page: with the page "full" its first round is refused
                     // (or is a bare sentinel), nothing is assembled or flushed, and the page ends with `bad` set
                     if (!tables_ok) { bad = true; out_pos = flushed = job.out_size; }
+                    if (kAblate & kAblRounds) live = false;             // (timing build: what the page starts alone cost)
                 }
                 clk.lap(kPhTables);
             }
         }
+        if ((kAblate & kAblRounds) && wave::any(!finished)) continue;
         if (!wave::any(live)) break;                                    // a half without a page has none left to take
         const bool in_page = live;
 
