@@ -24,6 +24,10 @@ python profiles/tools/cpu_decode_bench.py > "$out/cpu_decode.json" 2>> "$out/ben
 for k in "mixed 16" "text 16" "runs 16" "bc3 64" "samples16 16" "records 16"; do python profiles/phase_profile.py $k; done > "$out/phase_profile.jsonl" 2>> "$out/bench.err"
 BROTLIG_ENCODER_FLAGS=192 python profiles/phase_profile.py mixed 4 >> "$out/phase_profile.jsonl" 2>> "$out/bench.err"      # the optimal-parse streams (`alt`), 4 streams: the encode is slow
 python profiles/tools/config5_projection.py --out "$out/config5_projection.json" > /dev/null 2>> "$out/bench.err"
+# round 5: when each wavefront of a launch came and went (the launch's tail), on the PRODUCT kernel built with -DBROTLIG_WAVE_TIMES=1
+if [ -f build/abv/lib_wavetimes.so ]; then
+  for w in mixed text; do BROTLIG_HIP_SO=$root/build/abv/lib_wavetimes.so python profiles/tools/wave_times.py --workload $w 2>> "$out/bench.err"; done > "$out/wave_times.jsonl"
+fi
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -o f -- python "$root/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$out/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o f -- python "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$out/pmc_fetch.log" 2>&1

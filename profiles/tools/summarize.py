@@ -14,8 +14,9 @@ for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16"
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, pre + name + ".json")
 shutil.copy(os.path.join(src, "phase_profile.jsonl"), pre + "phase_profile.jsonl")
-if os.path.exists(os.path.join(src, "page_latency.jsonl")):
-    shutil.copy(os.path.join(src, "page_latency.jsonl"), pre + "page_latency.jsonl")
+for extra in ("page_latency.jsonl", "wave_times.jsonl"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), pre + extra)
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
 
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
@@ -35,6 +36,21 @@ with open(pre + "kernel_trace_stats.md", "w") as f:
     f.write("\n`brotlig_decode_kernel` average under rocprofv3: %.3f ms (2 warm-up + 5 timed + 1 verification launch).  "
             "bench.py's own HIP-event average over the 5 timed launches of the un-profiled run of the same "
             "build: %.3f ms (`%s`).\n" % (dec_avg, bench["roofline"]["kernel_ms"], os.path.basename(pre + "bench.json")))
+
+bc3 = glob.glob(os.path.join(src, "trace_bc3", "**", "*kernel_stats.csv"), recursive=True)
+if bc3:
+    rows3 = list(csv.DictReader(open(bc3[0])))
+    with open(pre + "kernel_trace_stats_bc3.md", "w") as f:
+        f.write(f"# Round {int(rnd)}, {label} -- rocprofv3 --kernel-trace --stats, config 4 (256 BC3 textures, 4 GiB)\n\n")
+        f.write("Command (MI355X box, from /tmp with TMPDIR=/tmp): `rocprofv3 --kernel-trace --stats --output-format csv "
+                "-d gpurun_out/%s/trace_bc3 -o f -- python bench.py --workload bc3 --streams 256 --steps 5 --warmup 2 --no-cpu-baseline`\n\n" % tag)
+        f.write("| kernel | calls | total ns | average ns | % | min ns | max ns |\n|---|---|---|---|---|---|---|\n")
+        for r in rows3[:6]:
+            f.write("| `%s` | %s | %s | %d | %s | %s | %s |\n" % (r["Name"][:80], r["Calls"], r["TotalDurationNs"],
+                    float(r["AverageNs"]), r["Percentage"], r["MinNs"], r["MaxNs"]))
+        dk = [float(r["AverageNs"]) for r in rows3 if "brotlig_decondition_kernel" in r["Name"]]
+        if dk:
+            f.write("\n`brotlig_decondition_kernel`: %.3f ms for 4 GiB read + 4 GiB written = %.2f TB/s.\n" % (dk[0] / 1e6, 2 * 4294967296.0 / dk[0] / 1e3))
 
 def pmc(sub, counter):
     p = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)[0]
