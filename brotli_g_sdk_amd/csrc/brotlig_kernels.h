@@ -557,20 +557,27 @@ __device__ __forceinline__ uint32_t advance_mod(uint32_t r, uint32_t step, uint3
     return r;
 }
 
-// Lanes (0..17) of a half whose code-length symbol (kCodeLenOrder) is smaller than lane sl's: the ties of the canonical order.
-__device__ __forceinline__ uint32_t cl_smaller_lanes(uint32_t sl)
+// Lanes (0..17) of a half whose code-length symbol (kCodeLenOrder[lane]) is smaller than lane sl's: the ties of the canonical order.
+// kClSmaller[k] = sum over j of (kCodeLenOrder[j] < kCodeLenOrder[k]) << j; checked against the order at compile time below.  (Written out
+// and selected by a chain of compares: an indexed read would be a global load per lane, in front of the table build's first LDS access.)
+constexpr uint32_t kClSmaller[18] = {0x00010u, 0x00011u, 0x00013u, 0x00017u, 0x00000u, 0x0001Fu, 0x3FFBFu, 0x0003Fu, 0x3FEBFu, 0x000BFu, 0x002BFu, 0x006BFu, 0x00EBFu, 0x01EBFu, 0x03EBFu, 0x07EBFu, 0x0FEBFu, 0x1FEBFu};
+constexpr bool cl_smaller_matches_the_order()
 {
     constexpr uint8_t order[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};      // = kCodeLenOrder
-    uint32_t m = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < 18u; ++k) {
+    for (int k = 0; k < 18; ++k) {
         uint32_t mk = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 18u; ++j) mk |= (order[j] < order[k] ? 1u : 0u) << j;
-        m = sl == k ? mk : m;
+        for (int j = 0; j < 18; ++j) mk |= (order[j] < order[k] ? 1u : 0u) << j;
+        if (mk != kClSmaller[k]) return false;
     }
-    return m;
+    return true;
 }
+static_assert(cl_smaller_matches_the_order(), "kClSmaller must follow kCodeLenOrder");
+template <uint32_t K> __device__ __forceinline__ uint32_t cl_smaller_select(uint32_t sl, uint32_t m)
+{
+    if constexpr (K < 18u) return cl_smaller_select<K + 1u>(sl, sl == K ? kClSmaller[K] : m);
+    else return m;
+}
+__device__ __forceinline__ uint32_t cl_smaller_lanes(uint32_t sl) { return cl_smaller_select<0u>(sl, 0u); }
 
 // One prefix-code table: which LDS arrays it lives in.
 struct TableRef {
@@ -2535,12 +2542,16 @@ __device__ __forceinline__ void dc_texture(const DcTable* __restrict__ tp, const
     const uint32_t supers = t.item_prefix[t.num_mips] >> 8;
     // Streams decoded side by side (blockIdx.y) start at different super-tiles: textures of the same size sit
     // at power-of-two distances in memory, and walking them in step would hit the same HBM channels.
-    const uint32_t rot = supers ? ((s * 2654435761u) >> 8) % supers : 0u;
+    // (a multiply-high, not a remainder: `(hash >> 8) % supers` has two operands below 2^24, for which this toolchain lowers the division to
+    // ONE float reciprocal with a correction for a quotient that came out too small only -- 13258079 / 11 comes out one too LARGE
+    // (0.0909090936 x 13258079 rounds up to 1205280.0), the remainder was -1 & 0xFFFFFF, and the mip walk below ran off the table: a
+    // memory fault on the device in round 5's soak, for one texture in ten thousand; the simulator divides exactly and never saw it)
+    const uint32_t rot = (uint32_t)(((uint64_t)(s * 2654435761u) * supers) >> 32);
     for (uint32_t st0 = wid; st0 < supers; st0 += nwaves) {
         // the mip and super-tile coordinates are wave-uniform and go to the scalar unit
         const uint32_t st = wave::uniform(st0 + rot < supers ? st0 + rot : st0 + rot - supers);
         uint32_t m = 0;
-        while ((st << 8) >= t.item_prefix[m + 1]) ++m;
+        while (m + 1u < kMaxMips && (st << 8) >= t.item_prefix[m + 1]) ++m;     // (bounded by the table whatever it holds)
         const uint32_t W = t.w[m], H = t.h[m], pitch = t.pitch[m];
         const uint32_t mip_bytes0 = t.mip_off_bytes[m], mip_block0 = t.mip_off_blocks[m], swizzle = t.swizzle;
         const uint32_t per_row = (pitch + bb - 1u) / bb, tiles_x = (per_row + 31u) / 32u, supers_x = (tiles_x + kDcSuperTiles - 1u) / kDcSuperTiles;
@@ -2776,8 +2787,9 @@ __global__ void __launch_bounds__(64) brotlig_policy_kernel(DecodeArgs a)
     const bool ordered = a.order != nullptr && total <= a.order_cap;
     const uint32_t pairs = total / 2u, nsamp = min_u32(pairs, 256u);
     uint32_t differ = 0, valid = 0;
+    const uint32_t stride = nsamp ? pairs / nsamp : 0u;
     for (uint32_t j = lane; j < nsamp; j += 64u) {
-        const uint32_t g = 2u * (uint32_t)(((uint64_t)j * pairs) / nsamp);
+        const uint32_t g = 2u * (j * stride);                           // evenly spaced pairs (stride = pairs / nsamp, one exact division per wavefront)
         uint32_t sa, ua, sb, ub;
         page_sizes(a, ordered ? a.order[g] : g, total, sa, ua);
         page_sizes(a, ordered ? a.order[g + 1u] : g + 1u, total, sb, ub);

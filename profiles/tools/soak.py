@@ -21,12 +21,14 @@ api.DebugSetDecodeMode(mode)
 t0 = time.time(); bad = []
 B = 80
 for c in range(first, first + n_plain, B):
+    print('plain', c, file=sys.stderr, flush=True)      # (the last line before a fault names the batch)
     items = [random_plain(s) for s in range(c, min(c + B, first + n_plain))]
     streams = [E.encode(d, **kw) for d, kw in items]
     dec = api.BatchDecoder(streams); dec.poison_output(); dec.decode()
     for i, (d, kw) in enumerate(items):
         if not np.array_equal(dec.output(i), d): bad.append(("plain", c + i))
 for c in range(first, first + n_precon, B):
+    print('precon', c, file=sys.stderr, flush=True)
     items = [random_precon(s) for s in range(c, min(c + B, first + n_precon))]
     streams = [E.encode(t, precondition=pre, **kw) for t, pre, kw in items]
     dec = api.BatchDecoder(streams, out_sizes=[len(t) for t, _, _ in items]); dec.poison_output(); dec.decode()
@@ -38,6 +40,7 @@ valid = [E.encode(*random_plain(3)[:1], **random_plain(3)[1])]
 vref = random_plain(3)[0]
 statuses = {}
 for c in range(first, first + n_corrupt, 40):
+    print('corrupt', c, file=sys.stderr, flush=True)
     streams, sizes = [], []
     for s in range(c, min(c + 40, first + n_corrupt)):
         d, kw = random_plain(s)

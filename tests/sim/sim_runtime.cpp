@@ -6,6 +6,7 @@
 #include <unistd.h>
 
 namespace sim {
+uint32_t g_block_y = 0, g_grid_y = 1;
 
 WaveState g_waves[kMaxWaves];
 WaveState* g_cw = &g_waves[0];

@@ -92,8 +92,9 @@ inline uint32_t thread_now() { return (uint32_t)(cw().index * kLanes + cw().cur)
 
 // ---- HIP built-ins used by the kernels --------------------------------------------------------
 struct SimThreadIdx { uint32_t y = 0, z = 0; struct X { operator uint32_t() const { return sim::thread_now(); } } x; };
-struct SimBlockIdx { uint32_t y = 0, z = 0; struct X { operator uint32_t() const { return sim::cw().block; } } x; };
-struct SimGridDim { uint32_t y = 1, z = 1; struct X { operator uint32_t() const { return sim::cw().grid; } } x; };
+namespace sim { extern uint32_t g_block_y, g_grid_y; }     // the y dimension of the launch being simulated (set by the harness around run_grid; 0 of 1 by default)
+struct SimBlockIdx { uint32_t z = 0; struct X { operator uint32_t() const { return sim::cw().block; } } x; struct Y { operator uint32_t() const { return sim::g_block_y; } } y; };
+struct SimGridDim { uint32_t z = 1; struct X { operator uint32_t() const { return sim::cw().grid; } } x; struct Y { operator uint32_t() const { return sim::g_grid_y; } } y; };
 struct SimBlockDim { uint32_t y = 1, z = 1; uint32_t x = sim::kLanes; };
 static const SimBlockDim blockDim;
 static const SimThreadIdx threadIdx;

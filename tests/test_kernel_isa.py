@@ -34,3 +34,25 @@ def test_small_batch_and_deconditioning_kernels_do_not_spill():
         sym, start, size = isa_budget.kernel_symbol(co, name)
         scratch = [i["op"] for i in isa_budget.disassemble(co, sym) if i["op"].startswith("scratch_")]
         assert not scratch, (name, scratch[:8])
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles gfx950 without a GPU)")
+def test_no_kernel_divides_through_one_float_reciprocal():
+    """Round 5: `(hash >> 8) % supers` in the de-conditioning kernel had two operands below 2^24; this toolchain lowers such a division to a
+    single float reciprocal (v_rcp_iflag_f32, v_mul_f32, v_trunc_f32) with a correction for a quotient that is too SMALL only.  13258079 / 11
+    comes out one too large, the remainder was -1 & 0xFFFFFF, a table walk ran off its table: a GPU memory fault for one texture in ten
+    thousand (the simulator divides exactly).  The expression is a multiply-high now; this test keeps the lowering out of every kernel:
+    its signature is v_trunc_f32 (the exact 32-bit lowering and the kernels' own div_small / mod_u16 do not use it)."""
+    import isa_budget
+    co = isa_budget.build([], False)
+    text = isa_budget.sh([f"{isa_budget.LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co])
+    assert "v_rcp_iflag_f32" in text            # (the listing is what it should be: the exact lowerings are there)
+    assert "v_trunc_f32" not in text, "a kernel divides through one float reciprocal: check the operands' ranges and avoid the division"
+
+
+def test_the_float_reciprocal_division_is_inexact_for_24_bit_operands():
+    """The arithmetic of the lowering above, restated: trunc(float(a) * float(1 / b)) for a = 13258079, b = 11 is one too large."""
+    import numpy as np
+    a, b = np.float32(13258079), np.float32(11)
+    q = np.trunc(a * (np.float32(1) / b))
+    assert int(q) == 13258079 // 11 + 1
