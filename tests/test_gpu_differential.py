@@ -67,6 +67,24 @@ def test_random_preconditioned_streams(api, kernel_form):
         assert np.array_equal(dec.output(i), ref), (i, random_precon(i)[1])
 
 
+def test_soak_batch_260800_decondition_tile_rotation(api):
+    """Regression (round 5 soak): 80 valid pre-conditioned streams; stream 66 (BC1, 71 x 14 blocks, 2 mips = 11 super-tiles) made the
+    de-conditioning kernel's tile rotation `(hash >> 8) % 11` come out as 0xFFFFFF on the device -- a 24-bit remainder lowered to one float
+    reciprocal, one too large in the quotient -- and the kernel walked off its table: GPU memory access fault (the simulator divides exactly).
+    The rotation is a multiply-high now (tests/test_kernel_isa.py keeps the lowering out of the kernels)."""
+    texs, streams = [], []
+    for seed in range(260800, 260880):
+        tex, pre, kw = random_precon(seed)
+        texs.append((tex, pre))
+        streams.append(E.encode(tex, precondition=pre, **kw))
+    dec = api.BatchDecoder(streams, out_sizes=[len(t) for t, _ in texs])
+    dec.poison_output()
+    dec.decode()
+    for i, ((t, pre), s) in enumerate(zip(texs, streams)):
+        rc, ref = oracle_decode(s, out_size=len(t))
+        assert rc == 0 and np.array_equal(dec.output(i), ref), (260800 + i, pre)
+
+
 def _valid_reference(api):
     d, kw = random_plain(3)
     s = E.encode(d, **kw)
