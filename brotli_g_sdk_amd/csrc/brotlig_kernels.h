@@ -2333,7 +2333,7 @@ __device__ inline void duo_consumer(DuoLds& D, const DecodeArgs& a)
     }
 }
 
-__global__ void __launch_bounds__(128) brotlig_decode_duo_kernel(DecodeArgs a)
+__global__ void __launch_bounds__(128, 4) brotlig_decode_duo_kernel(DecodeArgs a)     // (4 wavefronts per SIMD = the 8 workgroups per compute unit its LDS allows: 128 registers -- round 5: the new table builder had taken 145)
 {
     __shared__ DuoLds D;
     const uint32_t t = threadIdx.x;

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r05_final
 ( time timeout 900 python -m pytest tests -m gpu -x -q ) > gpurun_out/r05_final/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" gpurun_out/r05_final/pytest.log | tail -2
-timeout 150 python profiles/tools/soak.py 250000 6400 900 1200 0 > gpurun_out/r05_final/soak_auto.json 2> gpurun_out/r05_final/soak.err; echo "soak auto rc=$?"; tail -c 300 gpurun_out/r05_final/soak_auto.json; echo
-timeout 150 python profiles/tools/soak.py 260000 6400 900 1200 1 > gpurun_out/r05_final/soak_one_wavefront.json 2>> gpurun_out/r05_final/soak.err; echo "soak mode 1 rc=$?"; tail -c 300 gpurun_out/r05_final/soak_one_wavefront.json; echo
+
+
 bash profiles/tools/collect.sh r05_final > gpurun_out/r05_final/collect.log 2>&1; echo "collect rc=$?"
 tail -1 gpurun_out/r05_final/bench.json | cut -c1-300

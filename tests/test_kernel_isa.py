@@ -27,13 +27,18 @@ def test_no_scratch_access_inside_a_round():
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles gfx950 without a GPU)")
 def test_small_batch_and_deconditioning_kernels_do_not_spill():
-    """The two-wavefront kernel (256 registers to spend) and the de-conditioning gather keep everything in registers."""
+    """The de-conditioning kernel keeps everything in registers (59 of them: eight wavefronts per SIMD).  The two-wavefront kernel is held to 128
+    registers (round 5: `__launch_bounds__(128, 4)` -- its LDS allows eight workgroups per compute unit, and the new table builder had taken
+    145 registers, i.e. six: 2 048 pages 1.10 against 0.83 ms); at 128 it keeps a handful of page-scope values in scratch -- three stores at page
+    start, three reloads -- and no more than that."""
     import isa_budget
     co = isa_budget.build([], False)
-    for name in ("brotlig_decode_duo_kernel", "brotlig_decondition_kernel"):
-        sym, start, size = isa_budget.kernel_symbol(co, name)
-        scratch = [i["op"] for i in isa_budget.disassemble(co, sym) if i["op"].startswith("scratch_")]
-        assert not scratch, (name, scratch[:8])
+    sym, start, size = isa_budget.kernel_symbol(co, "brotlig_decondition_kernel")
+    scratch = [i["op"] for i in isa_budget.disassemble(co, sym) if i["op"].startswith("scratch_")]
+    assert not scratch, ("brotlig_decondition_kernel", scratch[:8])
+    sym, start, size = isa_budget.kernel_symbol(co, "brotlig_decode_duo_kernel")
+    scratch = [i["op"] for i in isa_budget.disassemble(co, sym) if i["op"].startswith("scratch_")]
+    assert len(scratch) <= 8, ("brotlig_decode_duo_kernel", scratch)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles gfx950 without a GPU)")
