@@ -36,6 +36,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d "$out/pmc_sq2" -o f -- python "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/pmc_sq2.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --output-format csv -d "$out/pmc_sq3" -o f -- python "$root/bench.py" --steps 1 --warmup 1 --no-cpu-baseline > "$out/pmc_sq3.log" 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/pmc_tcc" -o f -- python "$root/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-alt-parse > "$out/pmc_tcc.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_bc3" -o f -- python "$root/bench.py" --workload bc3 --streams 256 --steps 5 --warmup 2 --no-cpu-baseline > "$out/trace_bc3.log" 2>&1
 # keep only what the summariser needs (the merge-back limit is 64 MiB)
 find "$out" -name '*_kernel_trace.csv' -size +8M -delete
 find "$out" -name '*agent_info*' -delete
