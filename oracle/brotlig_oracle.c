@@ -387,7 +387,8 @@ static void delta_decode(const DcParams* dc, size_t page_start, size_t page_end,
 typedef struct { uint32_t insert_len, copy_len, dist; } Cmd;
 #ifdef BROTLIG_ORACLE_TRACE
 static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_pos, uint32_t litcount, uint32_t rlit);
-static void brotlig_oracle_trace_literal(uint32_t j, uint32_t code_len);    /* literal j of the round (sub-stream j mod 32) and the length of its code */
+static void brotlig_oracle_trace_literal(uint32_t j, uint32_t code_len);
+static void brotlig_oracle_trace_symbol(int table, uint32_t v15, const uint16_t* codelens);   /* a symbol is about to be decoded from the 15-bit window v15 (MSB first) */    /* literal j of the round (sub-stream j mod 32) and the length of its code */
 #endif
 
 /* PageDecoder.cpp:65-268.  `in` is the SafeBuf of the whole compressed input,
@@ -451,6 +452,9 @@ static int pd_run(PageDecoder* pd, const SafeBuf* in, size_t in_size, size_t in_
                 Cmd c; c.dist = 0;
                 /* DecodeCommand, :290-320 */
                 uint32_t bits = g_rev15[ds_peek(&ds, 15)];
+#ifdef BROTLIG_ORACLE_TRACE
+                brotlig_oracle_trace_symbol(0, bits, pd->codelens[0]);
+#endif
                 ds_consume(&ds, pd->codelens[0][bits]);
                 uint32_t sym = pd->symbols[0][bits];
                 if (sym <= 704) {
@@ -462,6 +466,9 @@ static int pd_run(PageDecoder* pd, const SafeBuf* in, size_t in_size, size_t in_
                     uint32_t dcode = 0;
                     if (sym >= 128) {                              /* DecodeDistance, :338-343 */
                         uint32_t db = g_rev15[ds_peek(&ds, 15)];
+#ifdef BROTLIG_ORACLE_TRACE
+                        brotlig_oracle_trace_symbol(1, db, pd->codelens[1]);
+#endif
                         ds_consume(&ds, pd->codelens[1][db]);
                         dcode = pd->symbols[1][db];
                     }
@@ -502,6 +509,7 @@ static int pd_run(PageDecoder* pd, const SafeBuf* in, size_t in_size, size_t in_
                 uint32_t bits = g_rev15[ds_peek(&ds, 15)];                          /* DecodeLiteral, :322-327 */
 #ifdef BROTLIG_ORACLE_TRACE
                 brotlig_oracle_trace_literal(j, pd->codelens[2][bits]);
+                brotlig_oracle_trace_symbol(2, bits, pd->codelens[2]);
 #endif
                 ds_consume(&ds, pd->codelens[2][bits]);
                 if (lq_back < lq_end) *lq_back++ = (uint8_t)pd->symbols[2][bits];

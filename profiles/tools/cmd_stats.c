@@ -28,6 +28,20 @@ static __thread uint32_t t_win_base, t_page_out;
 /* round 5 ("two literals per LUT lookup"): how often do two consecutive literals of ONE sub-stream (j and j + 32 of a
  * round: what the kernel's literal loop decodes back to back) fit a table index of 8 / 10 / 12 bits together? */
 static struct { uint64_t lits, pairs, fit8, fit10, fit12, len_sum, len_hist[16]; } LP;
+/* how a symbol is decoded by the kernel's tables: one LUT read (code <= 8 bits), LUT + one read (longer, but every code under its 8-bit prefix has
+ * the same length: "subtree"), or the canonical search (longer, lengths differ under the prefix) -- per table (ICP, distance, literal) */
+static struct { uint64_t n[3], subtree[3], search[3]; uint64_t rounds_cmd, rounds_any_search[2]; } SY;
+static __thread int t_round_search[2];
+static void brotlig_oracle_trace_symbol(int k, uint32_t v, const uint16_t* codelens)
+{
+    uint32_t len = codelens[v];
+    __sync_fetch_and_add(&SY.n[k], 1);
+    if (len > 8) {
+        uint32_t p = v & ~127u;
+        if (codelens[p] == codelens[p | 127u]) __sync_fetch_and_add(&SY.subtree[k], 1);
+        else { __sync_fetch_and_add(&SY.search[k], 1); if (k < 2) t_round_search[k] = 1; }
+    }
+}
 static __thread uint32_t t_lane_len[32];
 static void brotlig_oracle_trace_literal(uint32_t j, uint32_t len)
 {
@@ -46,6 +60,8 @@ static int dbucket(uint32_t d) { return d < 8 ? 0 : d < 32 ? 1 : d < 128 ? 2 : d
 static void brotlig_oracle_trace_round(const Cmd* q, uint32_t n, uint32_t out_pos, uint32_t litcount, uint32_t rlit)
 {
     if (out_pos == 0) t_win_base = 0;
+    __sync_fetch_and_add(&SY.rounds_cmd, 1);
+    for (int k = 0; k < 2; ++k) { if (t_round_search[k]) __sync_fetch_and_add(&SY.rounds_any_search[k], 1); t_round_search[k] = 0; }
     uint32_t rel0[33], tot = 0;
     for (uint32_t k = 0; k < n; ++k) { rel0[k] = tot; tot += q[k].insert_len + q[k].copy_len; }
     rel0[n] = tot;
@@ -159,7 +175,7 @@ int main(int argc, char** argv)
         fclose(f);
         uint32_t osz = DecompressedSize(in);
         uint8_t* out = malloc((size_t)osz + 64);
-        memset(&S, 0, sizeof S); memset(&LP, 0, sizeof LP);
+        memset(&S, 0, sizeof S); memset(&LP, 0, sizeof LP); memset(&SY, 0, sizeof SY);
         int used = 0;
         int rc = brotlig_oracle_decode((uint32_t)sz, in, &osz, out, 1, &used);
         double pages = osz / 65536.0, R = (double)S.rounds, G = (double)S.groups;
@@ -176,6 +192,12 @@ int main(int argc, char** argv)
         printf(" \"literal_pairs\": {\"literals\": %llu, \"mean_code_bits\": %.2f, \"pairs_fitting_8_bits\": %.3f, \"10_bits\": %.3f, \"12_bits\": %.3f},\n",
                (unsigned long long)LP.lits, LP.lits ? (double)LP.len_sum / LP.lits : 0.0, LP.pairs ? (double)LP.fit8 / LP.pairs : 0.0,
                LP.pairs ? (double)LP.fit10 / LP.pairs : 0.0, LP.pairs ? (double)LP.fit12 / LP.pairs : 0.0);
+        printf(" \"symbol_paths\": {");
+        { const char* nm[3] = {"icp", "dist", "lit"};
+          for (int k = 0; k < 3; ++k) printf("\"%s\": {\"symbols\": %llu, \"one_more_read\": %.4f, \"canonical_search\": %.4f}, ", nm[k], (unsigned long long)SY.n[k],
+                                             SY.n[k] ? (double)SY.subtree[k] / SY.n[k] : 0.0, SY.n[k] ? (double)SY.search[k] / SY.n[k] : 0.0); }
+        printf("\"rounds_with_a_searching_lane_icp\": %.3f, \"dist\": %.3f},\n", SY.rounds_cmd ? (double)SY.rounds_any_search[0] / SY.rounds_cmd : 0.0,
+               SY.rounds_cmd ? (double)SY.rounds_any_search[1] / SY.rounds_cmd : 0.0);
         printf(" \"level_hist\": [");
         for (int l = 0; l < 12; ++l) printf("%s%.3f", l ? ", " : "", S.level_hist[l] / G);
         printf("], \"ins_hist(0,1,2-3,4-7,8-15,16-31,32-127,128+)\": [");
