@@ -18,6 +18,8 @@ n_precon = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 n_corrupt = int(sys.argv[4]) if len(sys.argv) > 4 else 400
 mode = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 api.DebugSetDecodeMode(mode)
+grid = int(os.environ.get("BROTLIG_SOAK_GRID", "0"))     # e.g. 2: the classic kernel on two wavefronts -- every batch two pages per wavefront, the form of the large batches
+if grid: api.DebugSetDecodeGrid(grid)
 t0 = time.time(); bad = []
 B = 80
 for c in range(first, first + n_plain, B):
@@ -60,5 +62,5 @@ for c in range(first, first + n_corrupt, 40):
         statuses["refused"] = statuses.get("refused", 0) + 1
     out, _ = api.DecodeGPU(valid[0])
     if not np.array_equal(out, vref): bad.append(("valid-after-corrupt", c))
-print(json.dumps({"decode_mode": mode, "first_seed": first, "plain": n_plain, "precon": n_precon, "corrupt": n_corrupt, "failures": bad[:20], "n_failures": len(bad),
+print(json.dumps({"decode_mode": mode, "forced_grid": grid, "first_seed": first, "plain": n_plain, "precon": n_precon, "corrupt": n_corrupt, "failures": bad[:20], "n_failures": len(bad),
                   "corrupt_batch_statuses": {str(k): v for k, v in statuses.items()}, "seconds": round(time.time() - t0, 1)}))
