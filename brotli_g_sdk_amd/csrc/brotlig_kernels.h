@@ -2685,8 +2685,8 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
 // -------------------------------------------------------------------------------------------
 // Page schedule.  The decode kernel runs two pages per wavefront and pays the maximum of the two in
 // every phase of a round, so it matters which pages meet: the same 4 GiB of mixed pages decode 12 %
-// faster when similar pages are neighbours.  Pages are therefore grouped into sixteen buckets by
-// compressed size relative to the page size (half an octave per bucket; stored pages last) and
+// faster when similar pages are neighbours.  Pages are therefore grouped into buckets by
+// compressed size relative to the page size (an eighth of an octave per bucket since round 5, see below; stored pages last) and
 // handed out bucket by bucket, dense pages first (they are the slow ones, which also shortens the
 // tail of the launch).  Two passes over the page tables: count, then scatter into `order`.
 
