@@ -875,7 +875,10 @@ extern "C" int BrotligEncode(uint32_t input_size, const uint8_t* src, uint32_t* 
     BrotligEncodeOptions o; memset(&o, 0, sizeof o);
     if (opt) o = *opt;
     const uint32_t page_size = o.page_size ? o.page_size : 65536;
-    if (page_size != 32768 && page_size != 65536 && page_size != 131072) return BROTLIG_ENC_ERROR_PAGE_SIZE;
+    // The header's two-bit page size index (inc/DataStream.h:33, :73-75: 32 KiB << index) has FOUR values.  The reference's encoder stops at
+    // BROTLIG_MAX_PAGE_SIZE = 128 KiB (inc/common/BrotligConstants.h:85), its decoders do not look: a stream with index 3 is 256 KiB pages to
+    // DecodeCPU, so the decode path has to take it and this input generator can produce it.
+    if (page_size != 32768 && page_size != 65536 && page_size != 131072 && page_size != 262144) return BROTLIG_ENC_ERROR_PAGE_SIZE;
     if (input_size == 0) return BROTLIG_ENC_ERROR_EMPTY;
     const uint64_t num_pages = ((uint64_t)input_size + page_size - 1) / page_size;
     if (num_pages > 65535) return BROTLIG_ENC_ERROR_TOO_MANY_PAGES;
@@ -925,7 +928,7 @@ extern "C" int BrotligEncode(uint32_t input_size, const uint8_t* src, uint32_t* 
     uint8_t* w = output;
     const uint32_t last = input_size % page_size;                     // inc/DataStream.h:49-58
     w[0] = 5; w[1] = 5 ^ 0xFF; w[2] = (uint8_t)num_pages; w[3] = (uint8_t)(num_pages >> 8);
-    uint32_t idx = page_size == 32768 ? 0 : page_size == 65536 ? 1 : 2;
+    uint32_t idx = page_size == 32768 ? 0 : page_size == 65536 ? 1 : page_size == 131072 ? 2 : 3;
     uint32_t w1 = idx | (last << 2) | ((o.precondition ? 1u : 0u) << 20);
     memcpy(w + 4, &w1, 4); w += 8;
     if (o.precondition) {                                              // inc/DataStream.h:89-98

@@ -31,7 +31,7 @@ enum {
 };
 
 typedef struct BrotligEncodeOptions {
-    uint32_t page_size;      /* 32768 / 65536 / 131072; 0 -> 65536 */
+    uint32_t page_size;      /* 32768 / 65536 / 131072 / 262144 (header index 3: beyond the reference encoder's maximum, within its decoders'); 0 -> 65536 */
     uint32_t npostfix;       /* 0..3 */
     uint32_t ndirect_m;      /* 0..15; NDIRECT = ndirect_m << npostfix */
     uint32_t flags;

@@ -15,7 +15,7 @@ constexpr uint32_t kDistAlphabet = 544;
 constexpr uint32_t kLitAlphabet = 256;
 constexpr uint32_t kSentinel = 704;
 constexpr uint32_t kMinPageSize = 32768;
-constexpr uint32_t kMaxPageSize = 131072;
+constexpr uint32_t kMaxPageSize = 131072;       // BROTLIG_MAX_PAGE_SIZE: what the reference's ENCODER stops at; the header's index 3 (256 KiB) decodes all the same
 constexpr uint32_t kMaxSubBlocks = 6;
 constexpr uint32_t kMaxMips = 32;
 

@@ -45,9 +45,12 @@ def encode(data, page_size=65536, npostfix=0, ndirect_m=0, flags=0, max_chain=0,
     """Encode `data` (bytes-like / uint8 array) into one .brotlig stream (uint8 array).
 
     precondition: None, or a dict(format=1..5, width_blocks, height_blocks, num_mips=1, swizzle=False,
-    delta=False, pitch_bytes=0, pitch_d3d12_aligned=False).
+    delta=False, pitch_bytes=0, pitch_d3d12_aligned=False); a `page_size` key in it overrides the argument (the test
+    cases carry their page size with the texture's description).
     """
     lib = _load()
+    if precondition and precondition.get("page_size"):
+        page_size = precondition["page_size"]
     src = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data,
                                dtype=np.uint8)
     o = _Options(page_size=page_size, npostfix=npostfix, ndirect_m=ndirect_m, flags=flags, max_chain=max_chain,

@@ -33,6 +33,10 @@ def plain_cases():
         ("records_smoothed_histograms", lambda: D.records(N, 22), dict(flags=E.SMOOTH_HISTOGRAMS)),       # code lengths with longer runs (more 16 / 17 tokens)
         ("text_32k_pages", lambda: D.text(N, 14), dict(page_size=32768)),
         ("mixed_128k_pages", lambda: D.mixed(3 * 65536 + 77, 15), dict(page_size=131072)),
+        # the header's fourth page size (index 3 = 256 KiB: beyond the reference ENCODER's maximum, inc/common/BrotligConstants.h:85, but what its
+        # decoders make of the index, inc/DataStream.h:73-75): positions of 18 bits, and distances only such a page can hold
+        ("mixed_256k_pages", lambda: D.mixed(2 * 262144 + 777, 23), dict(page_size=262144)),
+        ("far_matches_256k_pages", lambda: np.tile(D.random_bytes(150000, 31), 4)[:262144 + 99001], dict(page_size=262144)),
         ("skewed_long_codes", lambda: skewed(N, 16), {}),
         ("deep_literal_codes", lambda: np.minimum(np.random.default_rng(21).geometric(0.05, 200000) - 1, 255).astype(np.uint8), {}),   # 15-bit literal codes: their sub-tables overflow the page's second-level pool (canonical fallback)
         ("long_matches", lambda: np.tile(D.random_bytes(5000, 17), 40)[:N], {}),
@@ -66,7 +70,7 @@ def skewed(n, seed):
 
 def precon_cases():
     out = []
-    for name, fmt, w, h, mips, swz, delta, aligned, pitch in [
+    for name, fmt, w, h, mips, swz, delta, aligned, pitch, *page in [
         ("bc1_swz_delta", 1, 128, 128, 1, 1, 1, 0, 0),
         ("bc2_mips4", 2, 32, 32, 4, 1, 1, 0, 0),
         ("bc3_odd", 3, 64, 50, 1, 1, 1, 0, 0),
@@ -86,9 +90,16 @@ def precon_cases():
         ("bc3_wide_odd_pitch", 3, 128, 4, 1, 1, 0, 0, 128 * 16 + 7),
         ("bc4_wide_mips2", 4, 256, 6, 2, 1, 1, 0, 0),
         ("bc1_wide_tall", 1, 640, 34, 1, 1, 0, 0, 0),
+        # every other page size under pre-conditioning (the delta ranges and the conditioned offsets of a page start at index x page size)
+        ("bc1_pages_32k", 1, 300, 200, 1, 1, 1, 0, 0, 32768),
+        ("bc3_mips4_pages_128k", 3, 200, 120, 4, 1, 1, 0, 0, 131072),
+        ("bc5_aligned_mips3_pages_256k", 5, 129, 65, 3, 1, 1, 1, 0, 262144),
+        ("bc4_noswz_pages_256k", 4, 256, 256, 2, 0, 1, 0, 0, 262144),
     ]:
         pre = dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=swz, delta=delta,
                    pitch_d3d12_aligned=aligned, pitch_bytes=pitch)
+        if page:
+            pre["page_size"] = page[0]          # brotli_g_sdk_amd.encoder.encode takes it from here
         out.append((name, (lambda f=fmt, w=w, h=h, m=mips, a=aligned, p=pitch, s=len(out):
                            D.bc_texture(f, w, h, seed=100 + s, num_mips=m, aligned=bool(a), pitch_bytes=p)), pre))
     return out

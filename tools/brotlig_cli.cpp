@@ -40,7 +40,7 @@ void usage()
            "  filename          -> filename.brotlig (compress)\n"
            "  filename.brotlig  -> filename (decompress on the GPU)\n"
            "Options:\n"
-           " -pagesize <value>             : encode page size in bytes: 32768, 65536 (default) or 131072\n"
+           " -pagesize <value>             : encode page size in bytes: 32768, 65536 (default), 131072 or 262144\n"
            " -precondition                 : apply format-based pre-conditioning before compression\n"
            " -swizzle                      : 2x2 block swizzle (pre-conditioning only)\n"
            " -delta-encode                 : delta-encode the colour endpoints (pre-conditioning only)\n"
