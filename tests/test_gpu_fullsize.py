@@ -60,6 +60,32 @@ def test_config3_mixed_4gib_full_size(api):
     assert np.array_equal(dec.output(0), ref)
 
 
+def test_one_stream_of_65535_pages(api):
+    """The container's maximum: NumPages is 16 bits (inc/DataStream.h:32), so one stream holds at most 65 535 pages -- 4 GiB less one
+    page of output, the largest value `DecompressedSize` can return for 64 KiB pages, with page-table offsets and page positions just
+    below 2^32.  255 distinct mixed pages tiled 257 times, decoded as a batch of one (every repeat compared on the device, the stream's
+    status word clean) and through the reference's host-pointer entry `DecodeGPU` (SHA-256 of every 257th of the output)."""
+    import torch
+    from brotli_g_sdk_amd import datagen as D, encoder as E
+    data = D.mixed(255 * 65536, 3)
+    stream = D.tile_stream(E.encode(data), 257)
+    assert api.DecompressedSize(stream) == 65535 * 65536 == 0xFFFF0000
+    dec = api.BatchDecoder([stream])
+    dec.poison_output()
+    dec.decode()
+    torch.cuda.synchronize()
+    assert dec.stream_status() == (0, [0])
+    exp = torch.from_numpy(data).to(dec.device)
+    got = dec.d_out[dec.out_offs[0]:dec.out_offs[0] + dec.sizes[0]].view(257, -1)
+    assert bool((got == exp.unsqueeze(0)).all())
+    del dec, got, exp
+    out, ms = api.DecodeGPU(stream)
+    assert len(out) == 0xFFFF0000 and ms > 0.0
+    want = hashlib.sha256(data.tobytes()).digest()
+    for k in (0, 1, 128, 255, 256):
+        assert hashlib.sha256(out[k * len(data):(k + 1) * len(data)].tobytes()).digest() == want, k
+
+
 def test_config4_bc3_4gib_full_size(api):
     """configs[3]: 256 BC3 textures of 1024 x 1024 blocks (16 MiB, 256 pages each), swizzle + delta; 8 distinct
     textures repeated as whole streams ("BC7-style" is realised as BC3: the reference has BC1-BC5 only)."""
