@@ -138,13 +138,17 @@ struct Streams {
 // Code-length RLE tokens (mirror of src/common/BrotligUtils.cpp:76-228 as read back by
 // src/decoder/BrotligHuffmanTable.cpp:163-195).
 struct Token { uint8_t sym; uint8_t extra; };
-void rle_tokens(const std::vector<uint8_t>& depth, bool use_rle, std::vector<Token>& out)
+// `corners`: the token sequences the reference's DECODER accepts and its encoder never chooses (BrotligHuffmanTable.cpp:163-195: every
+// literal token -- a 0 too -- becomes the length that 16 repeats, 16 and 17 leave it alone): a non-zero run that follows a zero run coded
+// with 17 goes straight to 16 when the last literal still has its length, and every other zero run is a literal 0 followed by 16s.
+void rle_tokens(const std::vector<uint8_t>& depth, bool use_rle, std::vector<Token>& out, bool corners = false)
 {
     out.clear();
     const size_t n = depth.size();
     int prev_literal = 8;       // decoder's initial "previous" (BrotligHuffmanTable.cpp:149)
     bool last_was_zero_run = false;
     bool first = true;
+    uint32_t zero_runs = 0;
     size_t i = 0;
     while (i < n) {
         uint8_t v = depth[i];
@@ -156,10 +160,16 @@ void rle_tokens(const std::vector<uint8_t>& depth, bool use_rle, std::vector<Tok
             prev_literal = v; last_was_zero_run = false; first = false;
         } else if (v == 0) {
             if (first) { out.push_back({0, 0}); --left; prev_literal = 0; first = false; last_was_zero_run = false; }
+            if (corners && (zero_runs++ & 1u) && left >= 4) {           // 0, then 16s repeating it
+                if (prev_literal != 0) { out.push_back({0, 0}); --left; prev_literal = 0; }
+                while (left >= 3) { size_t k = std::min<size_t>(left, 6); out.push_back({16, (uint8_t)(k - 3)}); left -= k; }
+                last_was_zero_run = false;
+            }
             while (left >= 3) { size_t k = std::min<size_t>(left, 10); out.push_back({17, (uint8_t)(k - 3)}); left -= k; last_was_zero_run = true; }
             for (; left; --left) { out.push_back({0, 0}); prev_literal = 0; last_was_zero_run = false; }
         } else {
-            if (first || prev_literal != v || last_was_zero_run) { out.push_back({v, 0}); --left; prev_literal = v; last_was_zero_run = false; first = false; }
+            if (first || prev_literal != v || (last_was_zero_run && !corners)) { out.push_back({v, 0}); --left; prev_literal = v; first = false; }
+            last_was_zero_run = false;
             while (left >= 3) { size_t k = std::min<size_t>(left, 6); out.push_back({16, (uint8_t)(k - 3)}); left -= k; }
             for (; left; --left) out.push_back({v, 0});
         }
@@ -267,12 +277,12 @@ PrefixCode emit_prefix_code(Streams& S, const std::vector<uint32_t>& hist, uint3
             uint32_t other = used[0] == 0 ? 1 : 0;
             depth[other] = 1;
         }
-        rle_tokens(depth, !(flags & BROTLIG_ENC_NO_CODELEN_RLE), tk);
+        rle_tokens(depth, !(flags & BROTLIG_ENC_NO_CODELEN_RLE), tk, (flags & BROTLIG_ENC_RLE_DECODER_CORNERS) != 0);
         std::vector<uint32_t> thist(18, 0);
         for (auto& t : tk) ++thist[t.sym];
         uint32_t distinct = 0; for (uint32_t c : thist) distinct += c != 0;
         if (distinct < 2) {                                            // Appendix D.6: never a 1-symbol code-length code
-            rle_tokens(depth, true, tk);
+            rle_tokens(depth, true, tk, (flags & BROTLIG_ENC_RLE_DECODER_CORNERS) != 0);
             std::fill(thist.begin(), thist.end(), 0);
             for (auto& t : tk) ++thist[t.sym];
         }

@@ -30,6 +30,13 @@ def plain_cases():
         ("all_stored", lambda: D.text(N, 13), dict(flags=E.FORCE_STORED)),
         ("mixed_optimal_parse", lambda: D.mixed(3 * 65536 + 500, 19), dict(flags=E.OPTIMAL_PARSE | E.SEARCH_DIST_PARAMS)),
         ("mixed_dist_param_search", lambda: D.mixed(5 * 65536, 18), dict(flags=E.SEARCH_DIST_PARAMS)),    # NPOSTFIX / NDIRECT vary per page
+        # code-length tokens the reference's decoder accepts and its encoder never writes (16 straight after a 17-run: the last LITERAL length
+        # survives the zeros; a zero run as a literal 0 and 16s: a 0 is a length like any other to 16 -- BrotligHuffmanTable.cpp:163-195)
+        ("records_rle_decoder_corners", lambda: D.records(N, 24), dict(flags=E.RLE_DECODER_CORNERS)),
+        ("text_rle_decoder_corners_complex", lambda: D.text(N, 25), dict(flags=E.RLE_DECODER_CORNERS | E.FORCE_COMPLEX_TABLES)),
+        # eight clusters of eight equally likely byte values, eight unused values between them: equal lengths either side of every zero run
+        ("clustered_alphabet_rle_decoder_corners", lambda: (np.arange(64) // 8 * 16 + np.arange(64) % 8).astype(np.uint8)[
+            np.random.default_rng(27).integers(0, 64, N)], dict(flags=E.RLE_DECODER_CORNERS)),
         ("records_smoothed_histograms", lambda: D.records(N, 22), dict(flags=E.SMOOTH_HISTOGRAMS)),       # code lengths with longer runs (more 16 / 17 tokens)
         ("text_32k_pages", lambda: D.text(N, 14), dict(page_size=32768)),
         ("mixed_128k_pages", lambda: D.mixed(3 * 65536 + 77, 15), dict(page_size=131072)),
@@ -95,6 +102,12 @@ def precon_cases():
         ("bc3_mips4_pages_128k", 3, 200, 120, 4, 1, 1, 0, 0, 131072),
         ("bc5_aligned_mips3_pages_256k", 5, 129, 65, 3, 1, 1, 1, 0, 262144),
         ("bc4_noswz_pages_256k", 4, 256, 256, 2, 0, 1, 0, 0, 262144),
+        # the precondition header's limits (inc/DataStream.h:89-98: width and height in blocks are 15 bits + 1): the widest and the tallest texture,
+        # the widest with a full mip chain down to one block, and the smallest
+        ("bc1_width_32768", 1, 32768, 3, 1, 1, 1, 0, 0),
+        ("bc4_height_32768", 4, 3, 32768, 1, 1, 1, 0, 0),
+        ("bc1_width_32768_mips16_aligned", 1, 32768, 1, 16, 1, 1, 1, 0),
+        ("bc3_one_block", 3, 1, 1, 1, 1, 1, 0, 0),
     ]:
         pre = dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=swz, delta=delta,
                    pitch_d3d12_aligned=aligned, pitch_bytes=pitch)
