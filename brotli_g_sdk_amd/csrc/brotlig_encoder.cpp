@@ -233,8 +233,9 @@ PrefixCode emit_prefix_code(Streams& S, const std::vector<uint32_t>& hist, uint3
     for (uint32_t s = 0; s < alphabet; ++s) if (hist[s]) used.push_back(s);
     S.reset();
     const bool force_complex = (flags & BROTLIG_ENC_FORCE_COMPLEX_TABLES) != 0;
+    const bool corners = (flags & BROTLIG_ENC_DECODER_CORNERS) != 0;
     if (used.size() <= 1) {                                            // trivial
-        S.at().put(0, 2); S.at().put(0, 4);
+        S.at().put(0, 2); S.at().put(corners ? 15 : 0, 4);              // (the four bits the reader skips, BrotligHuffmanTable.cpp:87)
         S.at().put(used.empty() ? 0 : used[0], maxbits);
         S.reset();
         return pc;
@@ -255,7 +256,11 @@ PrefixCode emit_prefix_code(Streams& S, const std::vector<uint32_t>& hist, uint3
         std::vector<std::pair<uint8_t, uint32_t>> lst;
         for (uint32_t k = 0; k < nsym; ++k) lst.push_back({lens[idx][k], ord[k]});
         std::sort(lst.begin(), lst.end());
-        S.at().put(1, 2); S.at().put(nsym - 1, 2); S.at().put(sel, 1); S.at().put(0, 1);
+        // (the reader gives the k-th listed symbol the k-th code of the shape, BrotligHuffmanTable.cpp:100-116: symbols of one length may come in
+        // any order -- descending with `corners` --, and the sixth header bit is skipped)
+        if (corners) std::sort(lst.begin(), lst.end(), [](const std::pair<uint8_t, uint32_t>& a, const std::pair<uint8_t, uint32_t>& b) {
+            return a.first != b.first ? a.first < b.first : a.second > b.second; });
+        S.at().put(1, 2); S.at().put(nsym - 1, 2); S.at().put(sel, 1); S.at().put(corners ? 1 : 0, 1);
         for (uint32_t k = 0; k < nsym; ++k) {
             S.at().put(lst[k].second, maxbits);
             pc.depth[lst[k].second] = lens[idx][k];
@@ -277,12 +282,12 @@ PrefixCode emit_prefix_code(Streams& S, const std::vector<uint32_t>& hist, uint3
             uint32_t other = used[0] == 0 ? 1 : 0;
             depth[other] = 1;
         }
-        rle_tokens(depth, !(flags & BROTLIG_ENC_NO_CODELEN_RLE), tk, (flags & BROTLIG_ENC_RLE_DECODER_CORNERS) != 0);
+        rle_tokens(depth, !(flags & BROTLIG_ENC_NO_CODELEN_RLE), tk, (flags & BROTLIG_ENC_DECODER_CORNERS) != 0);
         std::vector<uint32_t> thist(18, 0);
         for (auto& t : tk) ++thist[t.sym];
         uint32_t distinct = 0; for (uint32_t c : thist) distinct += c != 0;
         if (distinct < 2) {                                            // Appendix D.6: never a 1-symbol code-length code
-            rle_tokens(depth, true, tk, (flags & BROTLIG_ENC_RLE_DECODER_CORNERS) != 0);
+            rle_tokens(depth, true, tk, (flags & BROTLIG_ENC_DECODER_CORNERS) != 0);
             std::fill(thist.begin(), thist.end(), 0);
             for (auto& t : tk) ++thist[t.sym];
         }
@@ -751,7 +756,10 @@ std::vector<uint8_t> encode_page_once(const uint8_t* data, uint32_t n, const Bro
     }
     if (Ssz >= n) return out;                                          // not smaller -> stored (PageEncoder.cpp:565-568)
     BitWriter h;
-    h.put(npostfix, 2); h.put(ndirect >> npostfix, 4); h.put(is_delta ? 1 : 0, 1); h.put(0, 1);
+    // (with BROTLIG_ENC_DECODER_CORNERS: IS_DELTA set on a page of a stream that is not pre-conditioned, where the reader drops it, PageDecoder.cpp:87-88,
+    // and the reserved bit set, :89)
+    const bool corners = (o.flags & BROTLIG_ENC_DECODER_CORNERS) != 0;
+    h.put(npostfix, 2); h.put(ndirect >> npostfix, 4); h.put((is_delta || (corners && !o.precondition)) ? 1 : 0, 1); h.put(corners ? 1 : 0, 1);
     h.put(minlen, bit_width((Ssz + kNumStreams - 1) / kNumStreams));
     h.put(dsb, bit_width(bit_width(Ssz - 1)));
     for (uint32_t i = 0; i < kNumStreams; ++i) h.put(len[i] - minlen, dsb);

@@ -28,7 +28,8 @@ enum {
     BROTLIG_ENC_SEARCH_DIST_PARAMS  = 1u << 6,  /* per page: pick NPOSTFIX / NDIRECT by estimated distance cost */
     BROTLIG_ENC_OPTIMAL_PARSE       = 1u << 7,  /* shortest-path parse under the symbol costs of a first (lazy) parse */
     BROTLIG_ENC_SMOOTH_HISTOGRAMS   = 1u << 8,  /* smooth symbol counts so that the code lengths run-length encode better (kept per code only when smaller) */
-    BROTLIG_ENC_RLE_DECODER_CORNERS = 1u << 9   /* code-length tokens the reference's decoder accepts and its encoder never writes: 16 straight after a 17-run, zero runs as 0 + 16s */
+    BROTLIG_ENC_DECODER_CORNERS     = 1u << 9   /* what the reference's decoder accepts and its encoder never writes: code-length token 16 straight after a 17-run, zero runs
+                                                   as 0 + 16s; reserved / skipped header bits set; IS_DELTA on a page of a plain stream; simple codes listed in descending order */
 };
 
 typedef struct BrotligEncodeOptions {

@@ -14,7 +14,7 @@ LITERALS_ONLY = 1 << 4
 FORCE_COMPLEX_TABLES = 1 << 5
 SEARCH_DIST_PARAMS = 1 << 6      # per page: NPOSTFIX / NDIRECT chosen by estimated distance cost
 OPTIMAL_PARSE = 1 << 7           # shortest-path parse under the symbol costs of a first (lazy) parse
-RLE_DECODER_CORNERS = 1 << 9     # code-length tokens the reference's decoder accepts and its encoder never writes (16 after a 17-run, zero runs as 0 + 16s)
+DECODER_CORNERS = 1 << 9         # what the reference's decoder accepts and its encoder never writes (code-length tokens, reserved bits, IS_DELTA on plain pages, simple-code order)
 SMOOTH_HISTOGRAMS = 1 << 8       # smoothed symbol counts for the prefix codes where that makes the page smaller
 
 FORMAT_BC1, FORMAT_BC2, FORMAT_BC3, FORMAT_BC4, FORMAT_BC5 = 1, 2, 3, 4, 5

@@ -32,11 +32,14 @@ def plain_cases():
         ("mixed_dist_param_search", lambda: D.mixed(5 * 65536, 18), dict(flags=E.SEARCH_DIST_PARAMS)),    # NPOSTFIX / NDIRECT vary per page
         # code-length tokens the reference's decoder accepts and its encoder never writes (16 straight after a 17-run: the last LITERAL length
         # survives the zeros; a zero run as a literal 0 and 16s: a 0 is a length like any other to 16 -- BrotligHuffmanTable.cpp:163-195)
-        ("records_rle_decoder_corners", lambda: D.records(N, 24), dict(flags=E.RLE_DECODER_CORNERS)),
-        ("text_rle_decoder_corners_complex", lambda: D.text(N, 25), dict(flags=E.RLE_DECODER_CORNERS | E.FORCE_COMPLEX_TABLES)),
+        # (the same flag sets the header bits the reader skips, IS_DELTA on these plain pages -- dropped by the reader, PageDecoder.cpp:87-88 -- and lists
+        # the symbols of simple codes in descending order: runs have trivial and simple codes)
+        ("runs_decoder_corners", lambda: D.runs(N, 28), dict(flags=E.DECODER_CORNERS)),
+        ("records_decoder_corners", lambda: D.records(N, 24), dict(flags=E.DECODER_CORNERS)),
+        ("text_decoder_corners_complex", lambda: D.text(N, 25), dict(flags=E.DECODER_CORNERS | E.FORCE_COMPLEX_TABLES)),
         # eight clusters of eight equally likely byte values, eight unused values between them: equal lengths either side of every zero run
-        ("clustered_alphabet_rle_decoder_corners", lambda: (np.arange(64) // 8 * 16 + np.arange(64) % 8).astype(np.uint8)[
-            np.random.default_rng(27).integers(0, 64, N)], dict(flags=E.RLE_DECODER_CORNERS)),
+        ("clustered_alphabet_decoder_corners", lambda: (np.arange(64) // 8 * 16 + np.arange(64) % 8).astype(np.uint8)[
+            np.random.default_rng(27).integers(0, 64, N)], dict(flags=E.DECODER_CORNERS)),
         ("records_smoothed_histograms", lambda: D.records(N, 22), dict(flags=E.SMOOTH_HISTOGRAMS)),       # code lengths with longer runs (more 16 / 17 tokens)
         ("text_32k_pages", lambda: D.text(N, 14), dict(page_size=32768)),
         ("mixed_128k_pages", lambda: D.mixed(3 * 65536 + 77, 15), dict(page_size=131072)),
