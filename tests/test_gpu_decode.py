@@ -166,6 +166,39 @@ def test_batch_of_streams(api):
         assert np.array_equal(dec.output(i), d), i
 
 
+def test_batch_of_twenty_thousand_small_streams(api):
+    """What an asset streamer hands over: thousands of small streams in one batch.  20 011 streams of 1 byte .. a page and a bit (96 distinct
+    ones, cycled), two of them damaged: the prepare kernel walks every header (32 per step), the page-to-stream search runs over 20 011
+    entries, the per-stream status comes back as one strided copy of 20 011 words -- every stream bit-exact, the two damaged ones named."""
+    rng = np.random.default_rng(91)
+    makers = [D.text, D.records, D.samples16, D.runs, D.mixed, D.random_bytes]
+    base = [makers[i % 6](int(rng.integers(1, 65536 + 3000)) if i % 5 else int(rng.integers(1, 40)), 3000 + i) for i in range(96)]
+    enc = [E.encode(d) for d in base]
+    n = 20011
+    pick = rng.integers(0, 96, n)
+    streams = [enc[k] for k in pick]
+    bad_a, bad_b = 7, n - 2
+    hb = streams[bad_a].copy(); hb[0] ^= 0x10; streams[bad_a] = hb                              # stream id damaged: refused by the prepare kernel
+    big = next(k for k in range(96) if len(base[k]) > 4096 and k % 6 != 5)                       # a compressed page, not a stored one
+    pb = enc[big].copy(); pick[bad_b] = big
+    pb[8 + 4 + 40:8 + 4 + 60] ^= 0x5A                                                            # bytes inside the first page (any result, no fault)
+    streams[bad_b] = pb
+    dec = api.BatchDecoder(streams, out_sizes=[len(base[k]) for k in pick])
+    dec.poison_output()
+    try:
+        dec.decode()
+    except api.BrotligError:
+        pass
+    rc, per = dec.stream_status()
+    assert len(per) == n and per[bad_a] == api.BROTLIG_ERROR_CORRUPT_STREAM
+    assert [i for i, r in enumerate(per) if r != api.BROTLIG_OK and i not in (bad_a, bad_b)] == []
+    out = dec.d_out.cpu().numpy()
+    for i in range(n):
+        if i not in (bad_a, bad_b):
+            d = base[pick[i]]
+            assert np.array_equal(out[dec.out_offs[i]:dec.out_offs[i] + len(d)], d), i
+
+
 def test_batch_mixed_plain_and_preconditioned(api):
     tex = D.bc_texture(3, 96, 64, seed=5)
     pre = dict(format=3, width_blocks=96, height_blocks=64, swizzle=1, delta=1)
