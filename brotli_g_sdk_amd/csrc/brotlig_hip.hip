@@ -209,13 +209,22 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
     return a;
 }
 
+// Stream headers -> page counts -> exclusive prefix: one workgroup per 64 streams, and for more than 64 streams a second launch that adds
+// what lies before each workgroup's streams (brotlig_prepare_finish_kernel).
+void launch_prepare(const DecodeArgs& a, hipStream_t s)
+{
+    const uint32_t groups = (a.num_streams + 63u) / 64u;
+    hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(groups), dim3(64), 0, s, a);
+    if (groups > 1u) hipLaunchKernelGGL(brotlig_prepare_finish_kernel, dim3(groups), dim3(64), 0, s, a);
+}
+
 // prepare (page counts -> prefix) then the persistent page-decode kernel; k0/k1 bracket the latter
 BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
 {
     Grids g;
     if (BROTLIG_ERROR e = grid_sizes(&g)) return e;
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(1), dim3(64), 0, s, a);
+    launch_prepare(a, s);
     if (a.order) {                                                      // page schedule: count, then scatter
         hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g.order), dim3(64), 0, s, a);
         hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, s, a);
@@ -687,7 +696,7 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, ws_bytes, d_scratch);
     a.prof = static_cast<unsigned long long*>(prof.p);
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), nullptr));
-    hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(1), dim3(64), 0, nullptr, a);
+    launch_prepare(a, nullptr);
     if (a.order) {
         hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g.order), dim3(64), 0, nullptr, a);
         hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, nullptr, a);

@@ -66,7 +66,9 @@ struct DcTable {
     uint32_t format;                        // 1..5 = BC1..BC5, 0 = unknown (one byte per block)
     uint32_t status;                        // kStatus* bits of THIS stream (every stream has a record, pre-conditioned or not): which asset of a
                                             // batch was damaged (BrotligDecodeBatchStreamStatus); the batch-wide OR stays in DecodeArgs::status[0]
-    uint32_t pad[32];
+    uint32_t chunk_pages;                   // in the record of every 64th stream: the pages of the 64 streams from it on (brotlig_prepare_kernel,
+                                            // one workgroup per 64 streams, to brotlig_prepare_finish_kernel)
+    uint32_t pad[31];
 };
 static_assert(sizeof(DcTable) == 1024, "DcTable is addressed as 1 KiB records");
 
@@ -2632,54 +2634,72 @@ __global__ void __launch_bounds__(64) brotlig_decondition_kernel(DecodeArgs a)
 }
 
 // -------------------------------------------------------------------------------------------
-// Kernel 1: page counts per stream -> exclusive prefix (one workgroup; streams <= a few thousand)
+// Kernel 1: page counts per stream -> exclusive prefix.  One workgroup per 64 streams.  A batch of up to 64 streams is done in this one
+// launch; for more, every workgroup leaves the prefix inside its 64 streams and their page total (DcTable::chunk_pages of its first stream),
+// and brotlig_prepare_finish_kernel adds what lies before.  (Rounds 1-4 walked all streams in ONE workgroup, 64 per step, every step a chain
+// of dependent loads -- descriptor, header, table: 1.3 ms for a batch of 65 536 small streams, a quarter of its whole decode; round 5,
+// profiles/experiments/r05_many_streams.md.)
 __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
 {
     const uint32_t lane = threadIdx.x;
-    uint32_t running = 0;
-    for (uint32_t base = 0; base < a.num_streams; base += 64u) {
-        const uint32_t s = base + lane;
-        uint32_t pages = 0;
-        if (s < a.num_streams) {
-            const uint8_t* p = a.in + a.streams[s].in_offset;
-            StreamInfo si;
-            const uint64_t in_off = a.streams[s].in_offset;
-            const uint64_t in_end = stream_in_end(a.streams[s], a.in_bytes), out_end = stream_out_end(a.streams[s], a.out_bytes);
-            const bool hdr_in = in_off + 8u <= in_end;
-            // Beyond the reference's two checks (src/BrotligDecoder.cpp:437-446): the page table must lie inside the
-            // stream, a short last page cannot be longer than a page, and the stream's pages must fit the region the
-            // caller gave it -- a damaged header must not send pages into a neighbouring stream's output.
-            bool ok = hdr_in && parse_stream_header(load_u32(p), load_u32(p + 4), si) &&
-                      in_off + si.header_bytes + 4ull * si.num_pages <= in_end && si.last_page_size <= si.page_size;
-            uint64_t usz = 0;
-            if (ok) {
-                usz = (uint64_t)si.num_pages * si.page_size - (si.last_page_size ? si.page_size - si.last_page_size : 0u);
-                ok = a.streams[s].out_offset + usz <= out_end;
-            }
-            if (ok) pages = si.num_pages;
-            else atomicOr(a.status, kStatusBadHeader);
-            DcTable& t = a.dc[s];
-            t.precon = 0;
-            t.status = ok ? 0u : kStatusBadHeader;                      // the stream's own status word (pages add kStatusBadPage)
-            if (pages && si.preconditioned) {
-                // the texture described by the precondition header is the stream's output (:478): the de-conditioning
-                // kernel writes all of it, whatever happened to the stream's pages
-                if (a.scratch == nullptr || usz > 0xFFFFFFFFull || !dc_init(t, load_u32(p + 8), load_u32(p + 12), (uint32_t)usz)) {
-                    t.precon = 0; pages = 0;                            // the reference has undefined behaviour here
-                    t.status = kStatusBadHeader;
-                    atomicOr(a.status, kStatusBadHeader);
-                } else atomicAdd(a.status + 2, 1u);
-            }
+    const uint32_t s = blockIdx.x * 64u + lane;
+    uint32_t pages = 0;
+    if (s < a.num_streams) {
+        const uint8_t* p = a.in + a.streams[s].in_offset;
+        StreamInfo si;
+        const uint64_t in_off = a.streams[s].in_offset;
+        const uint64_t in_end = stream_in_end(a.streams[s], a.in_bytes), out_end = stream_out_end(a.streams[s], a.out_bytes);
+        const bool hdr_in = in_off + 8u <= in_end;
+        // Beyond the reference's two checks (src/BrotligDecoder.cpp:437-446): the page table must lie inside the
+        // stream, a short last page cannot be longer than a page, and the stream's pages must fit the region the
+        // caller gave it -- a damaged header must not send pages into a neighbouring stream's output.
+        bool ok = hdr_in && parse_stream_header(load_u32(p), load_u32(p + 4), si) &&
+                  in_off + si.header_bytes + 4ull * si.num_pages <= in_end && si.last_page_size <= si.page_size;
+        uint64_t usz = 0;
+        if (ok) {
+            usz = (uint64_t)si.num_pages * si.page_size - (si.last_page_size ? si.page_size - si.last_page_size : 0u);
+            ok = a.streams[s].out_offset + usz <= out_end;
         }
-        const uint32_t lo = wave::half_scan_incl(pages);
-        const uint32_t lo_total = wave::half_bcast(lo, 31);
-        const uint32_t first_half_total = wave::bcast(lo_total, 0);
-        const uint32_t second_half_total = wave::bcast(lo_total, 32);
-        const uint32_t incl = lane < 32u ? lo : lo + first_half_total;
-        if (s < a.num_streams) a.page_base[s] = running + incl - pages;
-        running += first_half_total + second_half_total;
+        if (ok) pages = si.num_pages;
+        else atomicOr(a.status, kStatusBadHeader);
+        DcTable& t = a.dc[s];
+        t.precon = 0;
+        t.status = ok ? 0u : kStatusBadHeader;                      // the stream's own status word (pages add kStatusBadPage)
+        if (pages && si.preconditioned) {
+            // the texture described by the precondition header is the stream's output (:478): the de-conditioning
+            // kernel writes all of it, whatever happened to the stream's pages
+            if (a.scratch == nullptr || usz > 0xFFFFFFFFull || !dc_init(t, load_u32(p + 8), load_u32(p + 12), (uint32_t)usz)) {
+                t.precon = 0; pages = 0;                            // the reference has undefined behaviour here
+                t.status = kStatusBadHeader;
+                atomicOr(a.status, kStatusBadHeader);
+            } else atomicAdd(a.status + 2, 1u);
+        }
     }
-    if (lane == 0u) { a.page_base[a.num_streams] = running; a.work_counter[0] = 0u; }
+    const uint32_t lo = wave::half_scan_incl(pages);
+    const uint32_t lo_total = wave::half_bcast(lo, 31);
+    const uint32_t first_half_total = wave::bcast(lo_total, 0);
+    const uint32_t second_half_total = wave::bcast(lo_total, 32);
+    const uint32_t incl = lane < 32u ? lo : lo + first_half_total;
+    const uint32_t total = first_half_total + second_half_total;
+    if (s < a.num_streams) a.page_base[s] = incl - pages;
+    if (lane == 0u) {
+        if (gridDim.x == 1u) { a.page_base[a.num_streams] = total; a.work_counter[0] = 0u; }
+        else a.dc[s].chunk_pages = total;
+    }
+}
+
+// Kernel 1b (batches of more than 64 streams; same grid): the pages of all earlier workgroups' streams, added to this one's 64 entries.
+__global__ void __launch_bounds__(64) brotlig_prepare_finish_kernel(DecodeArgs a)
+{
+    const uint32_t lane = threadIdx.x, c = blockIdx.x;
+    uint32_t acc = 0;
+    for (uint32_t j = lane; j < c; j += 64u) acc += a.dc[j * 64u].chunk_pages;
+    const uint32_t lo = wave::half_scan_incl(acc);
+    const uint32_t lo_total = wave::half_bcast(lo, 31);
+    const uint32_t before = wave::bcast(lo_total, 0) + wave::bcast(lo_total, 32);
+    const uint32_t s = c * 64u + lane;
+    if (s < a.num_streams) a.page_base[s] += before;
+    if (c + 1u == gridDim.x && lane == 0u) { a.page_base[a.num_streams] = before + a.dc[c * 64u].chunk_pages; a.work_counter[0] = 0u; }
 }
 
 // -------------------------------------------------------------------------------------------

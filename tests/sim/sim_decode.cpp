@@ -15,6 +15,14 @@ using namespace brotlig;
 static uint32_t g_last_policy = 0;
 static int g_use_order = 1;      // page schedule on (the GPU host code only uses it for large batches)
 static void prepare_body(void* p) { brotlig_prepare_kernel(*(DecodeArgs*)p); }
+static void prepare_finish_body(void* p) { brotlig_prepare_finish_kernel(*(DecodeArgs*)p); }
+// the host's launch_prepare (csrc/brotlig_hip.hip): one workgroup per 64 streams, the second kernel for more than 64 streams
+static void run_prepare(DecodeArgs& a)
+{
+    const uint32_t groups = (a.num_streams + 63u) / 64u;
+    sim::run_grid(groups, prepare_body, &a);
+    if (groups > 1u) sim::run_grid(groups, prepare_finish_body, &a);
+}
 static void order_count_body(void* p) { brotlig_order_count_kernel(*(DecodeArgs*)p); }
 static void order_scatter_body(void* p) { brotlig_order_scatter_kernel(*(DecodeArgs*)p); }
 static void policy_body(void* p) { brotlig_policy_kernel(*(DecodeArgs*)p); }
@@ -63,7 +71,7 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     const int decode_grid = grid ? grid : 4;
     std::vector<uint16_t> far_syms((size_t)decode_grid * 2u * kFarSymStride, 0xFFFFu);     // stale garbage between pages, as on the device
     a.far_syms = far_syms.data();
-    sim::run_grid(1, prepare_body, &a);
+    run_prepare(a);
     if (a.order) { sim::run_grid(3, order_count_body, &a); sim::run_grid(3, order_scatter_body, &a); }
     if (g_host_rule_limit) {
         // as enqueue(): the policy kernel only when two pages can meet in a wavefront; both decode kernels, the device decides
@@ -127,7 +135,7 @@ extern "C" int sim_entropy_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* 
     std::vector<uint16_t> far_syms((size_t)decode_grid * 2u * kFarSymStride, 0xFFFFu);
     a.far_syms = far_syms.data();
     a.cmds = cmds; a.lits = lits; a.slot_hdr = hdr; a.cmd_cap = cmd_cap; a.lit_stride = lit_stride;
-    sim::run_grid(1, prepare_body, &a);
+    run_prepare(a);
     sim::run_grid(1, policy_body, &a);
     sim::run_grid(decode_grid, entropy_body, &a);
     if (g_run_assemble == 3) { sim::run_grid(decode_grid, assemble_page_body, &a, (int)kPageWaves); sim::run_grid(3, decond_body, &a); }

@@ -278,7 +278,8 @@ def test_sim_per_stream_status_names_the_damaged_streams(sim, duo, grid):
             assert np.array_equal(outs[i], d), i
 
 
-def test_sim_batch_of_two_thousand_small_streams(sim):
+@pytest.mark.parametrize("n,bad", [(2003, 1234), (63, 5), (65, 64), (128, 127), (129, 128), (193, 0)])
+def test_sim_batch_of_two_thousand_small_streams(sim, n, bad):
     """Thousands of small streams in one batch (an asset streamer's hand-over; the device test takes 20 011): the prepare kernel walks the
     headers 32 per step with a running page count, fetch_job searches the page-to-stream table, every stream has its status word.  2 003
     streams of 1 byte .. 5 KiB from 40 distinct ones, one of them with a damaged stream id: every other stream bit-exact and clean."""
@@ -286,10 +287,8 @@ def test_sim_batch_of_two_thousand_small_streams(sim):
     makers = [D.text, D.records, D.samples16, D.runs, D.mixed, D.random_bytes]
     base = [makers[i % 6](int(rng.integers(1, 5000)) if i % 4 else int(rng.integers(1, 30)), 4000 + i) for i in range(40)]
     enc = [E.encode(d) for d in base]
-    n = 2003
-    pick = rng.integers(0, 40, n)
+    pick = rng.integers(0, 40, n)                    # (the other sizes: around the 64 streams a workgroup of the prepare kernel takes)
     streams = [enc[k] for k in pick]
-    bad = 1234
     hb = streams[bad].copy(); hb[1] ^= 0x01; streams[bad] = hb
     sim.sim_stream_status.restype = ctypes.c_uint32
     sim.sim_stream_status.argtypes = [ctypes.c_uint32]
