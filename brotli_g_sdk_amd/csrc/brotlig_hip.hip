@@ -271,10 +271,11 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
     }
     if (k1) HIP_OK(hipEventRecord(k1, s));
     if (a.scratch != nullptr) {   // (without a scratch buffer no stream of the batch can be pre-conditioned: the prepare kernel rejects them)
-        // streams over y, each stream's super-tiles over the wavefronts of x; 32 wavefronts per CU in total
-        const unsigned gy = a.num_streams < 32u ? a.num_streams : 32u;
-        const unsigned gx = ((unsigned)g.decond + gy - 1u) / gy;
-        hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(gx, gy), dim3(64), 0, s, a);
+        // The batch's super-tiles (2 x 128 blocks: 2 or 4 KiB of texture) are one list, cut evenly over the wavefronts of this launch, 32 per CU
+        // at most; a small batch does not need them all (the count is an estimate -- the kernel divides whatever list it finds by the grid).
+        const uint64_t want = a.out_bytes / 4096u + a.num_streams;
+        const unsigned grid = want < (uint64_t)g.decond ? (unsigned)want : (unsigned)g.decond;
+        hipLaunchKernelGGL(brotlig_decondition_kernel, dim3(grid ? grid : 1u), dim3(64), 0, s, a);
     }
     HIP_OK(hipGetLastError());
     return BROTLIG_OK;

@@ -68,7 +68,11 @@ struct DcTable {
                                             // batch was damaged (BrotligDecodeBatchStreamStatus); the batch-wide OR stays in DecodeArgs::status[0]
     uint32_t chunk_pages;                   // in the record of every 64th stream: the pages of the 64 streams from it on (brotlig_prepare_kernel,
                                             // one workgroup per 64 streams, to brotlig_prepare_finish_kernel)
-    uint32_t pad[31];
+    uint32_t super_base;                    // de-conditioning super-tiles of all streams before this one (every stream has the word; a stream that is
+                                            // not pre-conditioned has none of its own): the batch's super-tiles are one list, cut evenly over the
+                                            // wavefronts of brotlig_decondition_kernel
+    uint32_t chunk_supers;                  // like chunk_pages
+    uint32_t pad[29];
 };
 static_assert(sizeof(DcTable) == 1024, "DcTable is addressed as 1 KiB records");
 
@@ -2527,8 +2531,9 @@ __device__ __forceinline__ void dc_gather_tiles(const uint32_t (&sso)[kNumSub], 
 
 // One texture: the wavefront `wid` of `nwaves` takes every nwaves-th super-tile.  `lds`: kDcLdsBytes of this wavefront's own.
 template <uint32_t kSizes, uint32_t kNumSub>
-__device__ __forceinline__ void dc_texture(const DcTable* __restrict__ tp, const uint8_t* __restrict__ cond, uint8_t* __restrict__ tex,
-                                           uint32_t s, uint32_t wid, uint32_t nwaves, uint8_t* lds)
+// Super-tiles st_first, st_first + step, ... < st_end of one texture, by one wavefront; returns the first one of that progression it did not take.
+__device__ __forceinline__ uint32_t dc_texture(const DcTable* __restrict__ tp, const uint8_t* __restrict__ cond, uint8_t* __restrict__ tex,
+                                               uint32_t st_first, uint32_t st_end, uint32_t step, uint8_t* lds)
 {
     // (the table -- written by the prepare kernel, constant here -- is read through the constant address space: every word a scalar load.  As
     // plain global memory, even behind __restrict__, its words came as one vector load per lane each, waited for in front of the loads they
@@ -2540,19 +2545,12 @@ __device__ __forceinline__ void dc_texture(const DcTable* __restrict__ tp, const
     uint32_t sso[kNumSub];
 #pragma unroll
     for (uint32_t sub = 0; sub < kNumSub; ++sub) sso[sub] = t.sub_stream_off[sub];
-    // item_prefix counts lanes x tiles (64 per tile of 2 x 32 chunks), every tile row padded to whole super-tiles: >> 8 = super-tiles
-    const uint32_t supers = t.item_prefix[t.num_mips] >> 8;
-    // Streams decoded side by side (blockIdx.y) start at different super-tiles: textures of the same size sit
-    // at power-of-two distances in memory, and walking them in step would hit the same HBM channels.
-    // (a multiply-high, not a remainder: `(hash >> 8) % supers` has two operands below 2^24, for which this toolchain lowers the division to
-    // ONE float reciprocal with a correction for a quotient that came out too small only -- 13258079 / 11 comes out one too LARGE
-    // (0.0909090936 x 13258079 rounds up to 1205280.0), the remainder was -1 & 0xFFFFFF, and the mip walk below ran off the table: a
-    // memory fault on the device in round 5's soak, for one texture in ten thousand; the simulator divides exactly and never saw it)
-    const uint32_t rot = (uint32_t)(((uint64_t)(s * 2654435761u) * supers) >> 32);
-    for (uint32_t st0 = wid; st0 < supers; st0 += nwaves) {
+    // (item_prefix counts lanes x tiles -- 64 per tile of 2 x 32 chunks --, every tile row padded to whole super-tiles: >> 8 = super-tiles)
+    uint32_t m = 0;
+    uint32_t st0 = st_first;
+    for (; st0 < st_end; st0 += step) {
         // the mip and super-tile coordinates are wave-uniform and go to the scalar unit
-        const uint32_t st = wave::uniform(st0 + rot < supers ? st0 + rot : st0 + rot - supers);
-        uint32_t m = 0;
+        const uint32_t st = wave::uniform(st0);
         while (m + 1u < kMaxMips && (st << 8) >= t.item_prefix[m + 1]) ++m;     // (bounded by the table whatever it holds)
         const uint32_t W = t.w[m], H = t.h[m], pitch = t.pitch[m];
         const uint32_t mip_bytes0 = t.mip_off_bytes[m], mip_block0 = t.mip_off_blocks[m], swizzle = t.swizzle;
@@ -2608,29 +2606,79 @@ __device__ __forceinline__ void dc_texture(const DcTable* __restrict__ tp, const
                 dc_gather_tiles<kSizes, kNumSub, 2u>(sso, cond, tex + mip_bytes0, bb, W, H, pitch, per_row, swizzle, mip_block0, tr, tc, lane);
         }
     }
+    return st0;
+}
+
+// log2 of the wavefronts of a gang of the de-conditioning kernel; -1: by the batch (see the kernel)
+#ifndef BROTLIG_TUNE_DC_GANG_LOG2
+#define BROTLIG_TUNE_DC_GANG_LOG2 -1
+#endif
+// Super-tiles first, first + step, ... < end of the BATCH's list (DcTable::super_base says where a stream's begin), by one wavefront.
+__device__ __forceinline__ void dc_walk(const DecodeArgs& a, uint32_t first, uint32_t end, uint32_t step, uint8_t* lds)
+{
+    if (first >= end) return;
+    // (the tables were written by the prepare kernels and are constant here: wave-uniform words through the constant address space are
+    // scalar loads)
+    const BROTLIG_CONSTANT_AS DcTable* const dc = (const BROTLIG_CONSTANT_AS DcTable*)a.dc;
+    // the stream `first` falls into: the last one whose super-tiles begin at or before it (streams without any share their successor's base and sort before it)
+    uint32_t s = 0;
+    for (uint32_t hi = a.num_streams; hi - s > 1u;) { const uint32_t mid = (s + hi) >> 1; if (dc[mid].super_base <= first) s = mid; else hi = mid; }
+    uint32_t i = first;
+    while (i < end && s < a.num_streams) {
+        const BROTLIG_CONSTANT_AS DcTable& t = dc[s];
+        const uint32_t base = t.super_base;
+        const uint32_t supers = t.precon ? t.item_prefix[t.num_mips] >> 8 : 0u;
+        if (supers == 0u || base + supers <= i || base > i) { ++s; continue; }        // (base > i: a table that is not a prefix -- nothing is touched)
+        const uint32_t st_first = i - base, st_end = end - base < supers ? end - base : supers;
+        const uint64_t off = a.streams[s].out_offset;
+        const uint8_t* cond = a.scratch + off;
+        uint8_t* tex = a.out + off;
+        const DcTable* tp = a.dc + s;
+        uint32_t next;
+        // per-format instantiations (sub-block sizes, four bits each, first sub-block lowest: dc_init)
+        switch (t.format) {
+        case 1: next = dc_texture<0x422u, 3u>(tp, cond, tex, st_first, st_end, step, lds); break;
+        case 2: next = dc_texture<0x4228u, 4u>(tp, cond, tex, st_first, st_end, step, lds); break;
+        case 3: next = dc_texture<0x422611u, 6u>(tp, cond, tex, st_first, st_end, step, lds); break;
+        case 4: next = dc_texture<0x611u, 3u>(tp, cond, tex, st_first, st_end, step, lds); break;
+        case 5: next = dc_texture<0x611611u, 6u>(tp, cond, tex, st_first, st_end, step, lds); break;
+        default: next = dc_texture<0x1u, 1u>(tp, cond, tex, st_first, st_end, step, lds); break;
+        }
+        i = base + next;
+        ++s;
+    }
 }
 
 __global__ void __launch_bounds__(64) brotlig_decondition_kernel(DecodeArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t seg_lds[kDcLdsBytes];
-    if (a.status[2] == 0u) return;                                      // no preconditioned stream in this batch
-    const uint32_t nwaves = gridDim.x, wid = blockIdx.x;
-    for (uint32_t s = blockIdx.y; s < a.num_streams; s += gridDim.y) {
-        const DcTable& t = a.dc[s];
-        if (!t.precon) continue;
-        const uint64_t base = a.streams[s].out_offset;
-        const uint8_t* cond = a.scratch + base;
-        uint8_t* tex = a.out + base;
-        // per-format instantiations (sub-block sizes, four bits each, first sub-block lowest: dc_init)
-        switch (t.format) {
-        case 1: dc_texture<0x422u, 3u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
-        case 2: dc_texture<0x4228u, 4u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
-        case 3: dc_texture<0x422611u, 6u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
-        case 4: dc_texture<0x611u, 3u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
-        case 5: dc_texture<0x611611u, 6u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
-        default: dc_texture<0x1u, 1u>(&t, cond, tex, s, wid, nwaves, seg_lds); break;
-        }
-    }
+    // The batch's super-tiles are ONE list -- stream after stream -- cut into equal runs, one per GANG of wavefronts (consecutive
+    // workgroups); the gang's wavefronts take the run's super-tiles in turn, and a run begins and ends wherever it does -- inside a texture,
+    // inside a mip, across streams that are not pre-conditioned.  Large textures (1 024 super-tiles = 4 MiB of BC3 and more on average) are
+    // walked by gangs of 256: at any moment a gang reads and writes one neighbourhood, and HBM sees a few dozen long sequential streams
+    // instead of one per wavefront (config 4: prepare + de-conditioning 1.68 ms with gangs of 256, 1.78 with gangs of one); anything smaller
+    // by gangs of one, a contiguous run per wavefront (4 096 textures of 64 KiB: 0.18 ms against 0.32).  (Until late in round 5 the streams
+    // were spread over blockIdx.y and each stream's super-tiles over the 256 wavefronts of blockIdx.x: right for the benchmark's 16 MiB
+    // textures -- 1.63 ms --, but a 64 KiB texture has 16 super-tiles: 4 096 of them took 0.53 ms, 1.0 TB/s instead of 5, a third of that
+    // batch's whole step; profiles/experiments/r05_many_textures.md.)
+    const uint32_t total = wave::uniform(a.status[5]);
+    if (total == 0u) return;                                            // no preconditioned stream in this batch
+    const uint32_t textures = wave::uniform(a.status[2]);
+    const uint32_t gl = BROTLIG_TUNE_DC_GANG_LOG2 >= 0 ? (uint32_t)BROTLIG_TUNE_DC_GANG_LOG2 : ((total >> 10) >= textures ? 8u : 0u);
+    const uint32_t G = 1u << gl;
+    const uint32_t gangs = (gridDim.x + G - 1u) >> gl, gang = blockIdx.x >> gl, member = blockIdx.x - (gang << gl);
+    const uint32_t members = gang + 1u < gangs ? G : gridDim.x - (gang << gl);
+    const uint32_t per_gang = (total + gangs - 1u) / gangs;
+    const uint32_t lo = wave::uniform(gang * per_gang);
+    if (lo >= total) return;
+    const uint32_t hi = per_gang < total - lo ? lo + per_gang : total;
+    // Gangs that run side by side start at different places of their runs: equal textures sit at power-of-two distances in memory, and
+    // walking them in step would hit the same HBM channels.  The start is a whole number of turns into the run (a multiply-high, not a
+    // remainder: DESIGN 6.0), the part before it comes last.
+    const uint32_t turns = (hi - lo) / members;                         // (32-bit operands: the exact division)
+    const uint32_t mid = lo + members * (uint32_t)(((uint64_t)(gang * 2654435761u) * turns) >> 32);
+    dc_walk(a, mid + member, hi, members, seg_lds);
+    dc_walk(a, lo + member, mid, members, seg_lds);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -2643,7 +2691,7 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t s = blockIdx.x * 64u + lane;
-    uint32_t pages = 0;
+    uint32_t pages = 0, supers = 0;
     if (s < a.num_streams) {
         const uint8_t* p = a.in + a.streams[s].in_offset;
         StreamInfo si;
@@ -2672,7 +2720,7 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
                 t.precon = 0; pages = 0;                            // the reference has undefined behaviour here
                 t.status = kStatusBadHeader;
                 atomicOr(a.status, kStatusBadHeader);
-            } else atomicAdd(a.status + 2, 1u);
+            } else { atomicAdd(a.status + 2, 1u); supers = t.item_prefix[t.num_mips] >> 8; }
         }
     }
     const uint32_t lo = wave::half_scan_incl(pages);
@@ -2681,10 +2729,15 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
     const uint32_t second_half_total = wave::bcast(lo_total, 32);
     const uint32_t incl = lane < 32u ? lo : lo + first_half_total;
     const uint32_t total = first_half_total + second_half_total;
-    if (s < a.num_streams) a.page_base[s] = incl - pages;
+    // the same for the de-conditioning super-tiles
+    const uint32_t su = wave::half_scan_incl(supers);
+    const uint32_t su_total = wave::half_bcast(su, 31);
+    const uint32_t su_first = wave::bcast(su_total, 0), su_second = wave::bcast(su_total, 32);
+    const uint32_t su_incl = lane < 32u ? su : su + su_first;
+    if (s < a.num_streams) { a.page_base[s] = incl - pages; a.dc[s].super_base = su_incl - supers; }
     if (lane == 0u) {
-        if (gridDim.x == 1u) { a.page_base[a.num_streams] = total; a.work_counter[0] = 0u; }
-        else a.dc[s].chunk_pages = total;
+        if (gridDim.x == 1u) { a.page_base[a.num_streams] = total; a.work_counter[0] = 0u; a.status[5] = su_first + su_second; }
+        else { a.dc[s].chunk_pages = total; a.dc[s].chunk_supers = su_first + su_second; }
     }
 }
 
@@ -2692,14 +2745,20 @@ __global__ void __launch_bounds__(64) brotlig_prepare_kernel(DecodeArgs a)
 __global__ void __launch_bounds__(64) brotlig_prepare_finish_kernel(DecodeArgs a)
 {
     const uint32_t lane = threadIdx.x, c = blockIdx.x;
-    uint32_t acc = 0;
-    for (uint32_t j = lane; j < c; j += 64u) acc += a.dc[j * 64u].chunk_pages;
+    uint32_t acc = 0, acc_su = 0;
+    for (uint32_t j = lane; j < c; j += 64u) { acc += a.dc[j * 64u].chunk_pages; acc_su += a.dc[j * 64u].chunk_supers; }
     const uint32_t lo = wave::half_scan_incl(acc);
     const uint32_t lo_total = wave::half_bcast(lo, 31);
     const uint32_t before = wave::bcast(lo_total, 0) + wave::bcast(lo_total, 32);
+    const uint32_t su = wave::half_scan_incl(acc_su);
+    const uint32_t su_total = wave::half_bcast(su, 31);
+    const uint32_t before_su = wave::bcast(su_total, 0) + wave::bcast(su_total, 32);
     const uint32_t s = c * 64u + lane;
-    if (s < a.num_streams) a.page_base[s] += before;
-    if (c + 1u == gridDim.x && lane == 0u) { a.page_base[a.num_streams] = before + a.dc[c * 64u].chunk_pages; a.work_counter[0] = 0u; }
+    if (s < a.num_streams) { a.page_base[s] += before; a.dc[s].super_base += before_su; }
+    if (c + 1u == gridDim.x && lane == 0u) {
+        a.page_base[a.num_streams] = before + a.dc[c * 64u].chunk_pages; a.work_counter[0] = 0u;
+        a.status[5] = before_su + a.dc[c * 64u].chunk_supers;
+    }
 }
 
 // -------------------------------------------------------------------------------------------

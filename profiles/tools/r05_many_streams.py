@@ -22,6 +22,13 @@ for n in (256, 2048, 20011, 65536):
     dec.decode()
     total, kern = dec.timed(3, 20)
     out_bytes = int(sum(len(base[k]) for k in pick))
+    import time
+    dec.stream_status()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        dec.stream_status()
+    status_ms = (time.perf_counter() - t0) / 5 * 1e3
     print(json.dumps({"streams": n, "decompressed_MB": round(out_bytes / 1e6, 1), "step_ms": round(total / 20, 4), "decode_kernel_ms": round(kern, 4),
-                      "outside_kernel_ms": round(total / 20 - kern, 4), "GBps_step": round(out_bytes / (total / 20) / 1e6, 1)}), flush=True)
+                      "outside_kernel_ms": round(total / 20 - kern, 4), "GBps_step": round(out_bytes / (total / 20) / 1e6, 1),
+                      "stream_status_call_ms": round(status_ms, 3)}), flush=True)
     del dec

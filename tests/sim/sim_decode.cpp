@@ -33,7 +33,7 @@ static uint64_t g_duo_launches = 0;
 extern "C" void sim_set_duo(int on) { g_duo = on; }
 extern "C" uint64_t sim_duo_launches() { return g_duo_launches; }
 static void decond_body(void* p) { brotlig_decondition_kernel(*(DecodeArgs*)p); }
-static uint32_t g_decond_gx = 3, g_decond_gy = 0;      // launch shape of the de-conditioning kernel (gy 0: one row of workgroups for all streams)
+static uint32_t g_decond_gx = 3, g_decond_gy = 0;      // workgroups of the de-conditioning kernel: gx x gy (one row; the two factors are history)
 extern "C" void sim_set_decond_grid(uint32_t gx, uint32_t gy) { g_decond_gx = gx ? gx : 3u; g_decond_gy = gy; }
 static void selftest_body(void* p) { brotlig_selftest_kernel((uint32_t*)p); }
 // the last batch's per-stream status words (DcTable::status; BrotligDecodeBatchStreamStatus reads the same words on the device)
@@ -88,12 +88,8 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
         if (g_duo) { ++g_duo_launches; a.duo_limit = 0xFFFFFFFFu; sim::run_grid(decode_grid, duo_body, &a, 2); a.duo_limit = 0u; }
         else sim::run_grid(decode_grid, decode_body, &a);
     }
-    {   // the de-conditioning launch as the host shapes it (csrc/brotlig_hip.hip enqueue()): streams over y, a stream's super-tiles over x
-        const uint32_t gy = g_decond_gy ? (num_streams < g_decond_gy ? num_streams : g_decond_gy) : 1u;
-        sim::g_grid_y = gy;
-        for (uint32_t y = 0; y < gy; ++y) { sim::g_block_y = y; sim::run_grid(g_decond_gx, decond_body, &a); }
-        sim::g_block_y = 0; sim::g_grid_y = 1;
-    }
+    // the de-conditioning launch (csrc/brotlig_hip.hip enqueue()): one row of workgroups, the batch's super-tiles cut evenly over them
+    sim::run_grid(g_decond_gx * (g_decond_gy ? g_decond_gy : 1u), decond_body, &a);
     *status_out = status_words[0];
     g_last_policy = status_words[3];
     g_stream_status.resize(num_streams);

@@ -300,6 +300,57 @@ def test_sim_batch_of_two_thousand_small_streams(sim, n, bad):
             assert np.array_equal(outs[i], base[pick[i]]), i
 
 
+@pytest.mark.parametrize("grid", [1, 2, 5, 64, 1000])
+def test_sim_decondition_cuts_the_batch_into_equal_runs(sim, grid):
+    """The de-conditioning kernel takes the super-tiles of ALL pre-conditioned streams of a batch as one list (DcTable::super_base, a prefix
+    the prepare kernels compute next to the page prefix) and gives every wavefront an equal run of it -- runs that begin and end anywhere:
+    inside a texture, inside a mip, across plain streams that have no super-tiles, across several one-block textures.  Eleven streams (plain
+    ones first, between and last; textures of one block, of many mips, wide, tall, of every format), with one wavefront for everything, with
+    fewer wavefronts than super-tiles, and with far more wavefronts than super-tiles."""
+    specs = [None, (3, 1, 1, 1), (1, 40, 24, 4), None, None, (5, 1, 1, 1), (2, 1, 1, 1), (4, 300, 6, 2), (3, 7, 90, 3), (1, 130, 130, 8), None]
+    streams, sizes, want = [], [], []
+    for k, sp in enumerate(specs):
+        if sp is None:
+            d = D.mixed(30000 + 999 * k, 600 + k)
+            streams.append(E.encode(d)); sizes.append(len(d)); want.append(d)
+        else:
+            fmt, w, h, mips = sp
+            tex = D.bc_texture(fmt, w, h, seed=700 + k, num_mips=mips)
+            st = E.encode(tex, precondition=dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=1, delta=1))
+            rc, ref = oracle_decode(st, out_size=len(tex))
+            assert rc == 0
+            streams.append(st); sizes.append(len(tex)); want.append(ref)
+    sim.sim_set_decond_grid(grid, 0)
+    try:
+        outs, status = run_batch(sim, streams, sizes, precon=True, grid=4)
+    finally:
+        sim.sim_set_decond_grid(3, 0)
+    assert status == 0
+    for k in range(len(specs)):
+        assert np.array_equal(outs[k], want[k]), (k, specs[k])
+
+
+@pytest.mark.parametrize("grid", [8, 300])
+def test_sim_decondition_large_textures_go_to_gangs_of_256(sim, grid):
+    """A batch whose textures have 1 024 super-tiles and more on average (4 MiB of BC3) is walked by gangs of 256 wavefronts that take a
+    run's super-tiles in turn (large textures: HBM sees a few long streams); the same bytes with fewer wavefronts than a gang (one short
+    gang) and with a full gang plus a short one.  Two textures, the rotation point of a run inside either."""
+    specs = [(1, 1024, 256, 1), (4, 1024, 258, 2)]
+    streams, sizes, want = [], [], []
+    for k, (fmt, w, h, mips) in enumerate(specs):
+        tex = D.bc_texture(fmt, w, h, seed=800 + k, num_mips=mips)
+        st = E.encode(tex, precondition=dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=1, delta=1))
+        streams.append(st); sizes.append(len(tex)); want.append(tex)
+    sim.sim_set_decond_grid(grid, 0)
+    try:
+        outs, status = run_batch(sim, streams, sizes, precon=True, grid=16)
+    finally:
+        sim.sim_set_decond_grid(3, 0)
+    assert status == 0
+    for k in range(len(specs)):
+        assert np.array_equal(outs[k], want[k]), k
+
+
 def test_sim_host_rule_exactly_one_kernel_decodes(sim):
     """The host launches BOTH page kernels when the output size leaves the page count open, and the device decides (DecodeArgs::duo_limit
     against the page count the prepare kernel found); it skips the policy kernel when no two pages can meet (csrc/brotlig_hip.hip enqueue()).
