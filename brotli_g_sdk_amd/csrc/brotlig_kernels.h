@@ -83,8 +83,9 @@ struct DecodeArgs {
     const StreamDesc* streams; uint32_t num_streams;
     uint32_t* page_base;    // [num_streams + 1] exclusive prefix of page counts
     uint32_t* work_counter; // [1] next global page index
-    uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams, [3] pairing policy,
-                            // [8..8+B) pages per scheduling bucket, [8+B..8+2B) bucket fill cursors (B = kBuckets <= 64; kStatusWords in all)
+    uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams, [3] pairing policy, [5] de-conditioning super-tiles of the
+                            // batch (the end of the DcTable::super_base prefix), [8..8+B) pages per scheduling bucket, [8+B..8+2B) bucket fill
+                            // cursors (B = kBuckets <= 64; kStatusWords in all)
     uint32_t* order;        // [order_cap] page schedule: global page indices grouped by bucket (null: page order)
     uint32_t  order_cap;
     uint32_t  duo_limit;    // batches of up to this many pages belong to brotlig_decode_duo_kernel (two wavefronts per page), larger ones to
