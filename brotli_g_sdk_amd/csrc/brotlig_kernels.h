@@ -2352,6 +2352,17 @@ __global__ void __launch_bounds__(128, 4) brotlig_decode_duo_kernel(DecodeArgs a
     if (t < 64u) duo_producer(D, a); else duo_consumer(D, a);
 }
 
+// NARROW mips (late round 5).  Under the 2 x 2 swizzle (PageDecoder.cpp:416-436) a pair of texture rows is 2 W consecutive blocks of every
+// conditioned sub-stream, whatever W: a mip narrower than a super-tile's 128 columns -- W a power of two, H even, rows without padding -- is
+// cut into super-tiles of 128 / W row pairs instead of one, each again 256 CONSECUTIVE blocks per sub-stream (the wide path's shape; before,
+// such mips went through the per-block gather, one half-empty super-tile per row pair).  Returns log2 of the row pairs per super-tile
+// (0: one, the general case).  dc_init counts the super-tiles with it, dc_texture walks them with it.
+__device__ __forceinline__ uint32_t dc_row_group_log2(uint32_t W, uint32_t H, uint32_t pitch, uint32_t bb, uint32_t swizzle)
+{
+    const bool narrow = swizzle != 0u && W >= 2u && W < 128u && (W & (W - 1u)) == 0u && (H & 1u) == 0u && pitch == W * bb;
+    return narrow ? 7u - (31u - (uint32_t)__clz((int)W)) : 0u;
+}
+
 // -------------------------------------------------------------------------------------------
 // Pre-conditioning tables (inc/common/BrotligDataConditioner.h:92-237).  `w0`/`w1` are the two
 // dwords of the PreconditionHeader; `out_size` is the stream's decompressed size, which must equal
@@ -2395,7 +2406,8 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
         if ((uint64_t)t.pitch[m] < (uint64_t)t.w[m] * bb) fits = false;
         total += (uint64_t)t.w[m] * t.h[m];
         bytes += (uint64_t)t.pitch[m] * t.h[m];
-        items += (uint64_t)((t.h[m] + 1u) / 2u) * ((((t.pitch[m] + bb - 1u) / bb + 31u) / 32u + 3u) / 4u) * 256u;    // tile rows of whole super-tiles (4 tiles)
+        const uint32_t rg = dc_row_group_log2(t.w[m], t.h[m], t.pitch[m], bb, t.swizzle);                       // (narrow mips: 128 / W tile rows per super-tile)
+        items += (uint64_t)((((t.h[m] + 1u) / 2u) + (1u << rg) - 1u) >> rg) * ((((t.pitch[m] + bb - 1u) / bb + 31u) / 32u + 3u) / 4u) * 256u;    // tile rows of whole super-tiles (4 tiles)
         if (bytes > (uint64_t)out_size || total * bb > (uint64_t)out_size || items > 0xFFFFFFFFull) fits = false;
         t.mip_off_bytes[m + 1] = fits ? (uint32_t)bytes : 0u;
         t.mip_off_blocks[m + 1] = fits ? (uint32_t)total : 0u;
@@ -2530,9 +2542,9 @@ __device__ __forceinline__ void dc_gather_tiles(const uint32_t (&sso)[kNumSub], 
     }
 }
 
-// One texture: the wavefront `wid` of `nwaves` takes every nwaves-th super-tile.  `lds`: kDcLdsBytes of this wavefront's own.
-template <uint32_t kSizes, uint32_t kNumSub>
 // Super-tiles st_first, st_first + step, ... < st_end of one texture, by one wavefront; returns the first one of that progression it did not take.
+// `lds`: kDcLdsBytes of this wavefront's own.
+template <uint32_t kSizes, uint32_t kNumSub>
 __device__ __forceinline__ uint32_t dc_texture(const DcTable* __restrict__ tp, const uint8_t* __restrict__ cond, uint8_t* __restrict__ tex,
                                                uint32_t st_first, uint32_t st_end, uint32_t step, uint8_t* lds)
 {
@@ -2557,13 +2569,17 @@ __device__ __forceinline__ uint32_t dc_texture(const DcTable* __restrict__ tp, c
         const uint32_t mip_bytes0 = t.mip_off_bytes[m], mip_block0 = t.mip_off_blocks[m], swizzle = t.swizzle;
         const uint32_t per_row = (pitch + bb - 1u) / bb, tiles_x = (per_row + 31u) / 32u, supers_x = (tiles_x + kDcSuperTiles - 1u) / kDcSuperTiles;
         const uint32_t local = st - (t.item_prefix[m] >> 8);
-        const uint32_t tr = local / supers_x, q = local - tr * supers_x;
-        const bool wide = BROTLIG_TUNE_DC_WIDE && bbK >= 8u && bb == bbK && swizzle != 0u && ((W | H) & 1u) == 0u && 2u * tr + 1u < H &&
-                          kDcSuperCols * (q + 1u) <= W && ((mip_bytes0 | pitch) & (bbK - 1u)) == 0u;
+        const uint32_t trg = local / supers_x, q = local - trg * supers_x;
+        // the super-tile's tile rows (pairs of texture rows): one, or 128 / W of a narrow mip (then supers_x is 1 and q is 0)
+        const uint32_t rg = dc_row_group_log2(W, H, pitch, bb, swizzle);
+        const uint32_t tile_rows = (H + 1u) >> 1, tr0 = trg << rg, tr1 = ((trg + 1u) << rg) < tile_rows ? (trg + 1u) << rg : tile_rows;
+        const uint32_t lw = 7u - rg;                                            // log2 of the super-tile's columns
+        const bool wide = BROTLIG_TUNE_DC_WIDE && bbK >= 8u && bb == bbK && swizzle != 0u && ((W | H) & 1u) == 0u && ((mip_bytes0 | pitch) & (bbK - 1u)) == 0u &&
+                          (rg ? ((trg + 1u) << rg) <= tile_rows : (2u * tr0 + 1u < H && kDcSuperCols * (q + 1u) <= W));
         if (wide) {
             if constexpr (bbK >= 8u) {
                 // first block of the super-tile in conditioned order: block(row, col) = 2 (row / 2) W + 4 (col / 2) + 2 (row & 1) + (col & 1)
-                const uint32_t g0 = mip_block0 + 2u * tr * W + kDcSuperBlocks * q;
+                const uint32_t g0 = mip_block0 + 2u * tr0 * W + kDcSuperBlocks * q;
                 constexpr uint32_t kLoads = bbK / 4u;                           // 16-byte units: 16 bbK of them, 64 per load instruction
                 Bytes16 seg[kLoads];
 #pragma unroll
@@ -2581,11 +2597,13 @@ __device__ __forceinline__ uint32_t dc_texture(const DcTable* __restrict__ tp, c
 #pragma unroll
                 for (uint32_t i = 0; i < kLoads; ++i) store16(lds + 16u * (64u * i + lane), seg[i]);
                 wave::sync();
-                uint8_t* const row0 = tex + mip_bytes0 + 2u * tr * pitch + kDcSuperCols * q * bbK;
+                uint8_t* const row0 = tex + mip_bytes0 + 2u * tr0 * pitch + kDcSuperCols * q * bbK;
+                const uint32_t cmask = (1u << lw) - 1u;
 #pragma unroll BROTLIG_TUNE_DC_ASM_UNROLL
                 for (uint32_t i = 0; i < kDcSuperBlocks / 64u; ++i) {
-                    const uint32_t idx = 64u * i + lane, r = idx / kDcSuperCols, c = idx % kDcSuperCols;
-                    const uint32_t j = 4u * (c >> 1) + 2u * r + (c & 1u);       // the block's place among the super-tile's 256, conditioned order
+                    // block idx of the super-tile in TEXTURE order: row r (of 2 .. 128), column c (of 128 .. 2)
+                    const uint32_t idx = 64u * i + lane, r = idx >> lw, c = idx & cmask;
+                    const uint32_t j = ((r >> 1) << (lw + 1u)) + 4u * (c >> 1) + 2u * (r & 1u) + (c & 1u);       // its place among the 256, conditioned order
                     uint64_t v[kNumSub];
 #pragma unroll
                     for (uint32_t sub = 0; sub < kNumSub; ++sub) {
@@ -2603,8 +2621,11 @@ __device__ __forceinline__ uint32_t dc_texture(const DcTable* __restrict__ tp, c
         } else {
             // two tiles at a time (four at once cost more registers than their loads in flight bring: round 4, 79 VGPRs)
 #pragma nounroll
-            for (uint32_t tc = kDcSuperTiles * q; tc < kDcSuperTiles * (q + 1u) && tc < tiles_x; tc += 2u)
-                dc_gather_tiles<kSizes, kNumSub, 2u>(sso, cond, tex + mip_bytes0, bb, W, H, pitch, per_row, swizzle, mip_block0, tr, tc, lane);
+            for (uint32_t tr = tr0; tr < tr1; ++tr) {
+#pragma nounroll
+                for (uint32_t tc = kDcSuperTiles * q; tc < kDcSuperTiles * (q + 1u) && tc < tiles_x; tc += 2u)
+                    dc_gather_tiles<kSizes, kNumSub, 2u>(sso, cond, tex + mip_bytes0, bb, W, H, pitch, per_row, swizzle, mip_block0, tr, tc, lane);
+            }
         }
     }
     return st0;

@@ -111,6 +111,18 @@ def precon_cases():
         ("bc4_height_32768", 4, 3, 32768, 1, 1, 1, 0, 0),
         ("bc1_width_32768_mips16_aligned", 1, 32768, 1, 16, 1, 1, 1, 0),
         ("bc3_one_block", 3, 1, 1, 1, 1, 1, 0, 0),
+        # narrow swizzled mips (a power of two below 128 columns, even height, no row padding): super-tiles of 128 / W row pairs, 256 consecutive
+        # blocks of every sub-stream each -- whole groups through the wide path, the last group of a mip (fewer row pairs) through the gather, and
+        # next to them the shapes that must NOT be taken for narrow: an odd height, padded rows, no swizzle, 128 columns exactly
+        ("bc3_narrow_64x64", 3, 64, 64, 1, 1, 1, 0, 0),
+        ("bc1_narrow_32x32_mips6", 1, 32, 32, 6, 1, 1, 0, 0),
+        ("bc5_narrow_16x40", 5, 16, 40, 1, 1, 0, 0, 0),                 # 20 row pairs in groups of 8: two whole groups and four pairs
+        ("bc4_narrow_2x200", 4, 2, 200, 1, 1, 1, 0, 0),                 # 100 row pairs in groups of 64
+        ("bc2_narrow_64x10_mips3_aligned", 2, 64, 10, 3, 1, 1, 1, 0),   # 64 x 10 narrow (1 KiB rows), 32 x 5 odd, 16 x 2 with rows padded to 256 bytes
+        ("bc3_narrow_64x6_pitchpad", 3, 64, 6, 1, 1, 1, 0, 64 * 16 + 16),
+        ("bc1_narrow_64x64_noswizzle", 1, 64, 64, 1, 0, 1, 0, 0),
+        ("bc5_128x8_exactly", 5, 128, 8, 2, 1, 1, 0, 0),                # 128 columns: the general wide path; its 64 x 4 mip: narrow, one whole group
+        ("bc3_narrow_8x512_mips4", 3, 8, 512, 4, 1, 1, 0, 0),           # 8, 4, 2 columns narrow; the 1 x 64 mip is not
     ]:
         pre = dict(format=fmt, width_blocks=w, height_blocks=h, num_mips=mips, swizzle=swz, delta=delta,
                    pitch_d3d12_aligned=aligned, pitch_bytes=pitch)
