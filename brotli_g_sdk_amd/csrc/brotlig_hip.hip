@@ -186,9 +186,15 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
     const size_t base = workspace_bytes(n);
     const uint64_t room = ws_bytes > base ? (ws_bytes - base) / 4u : 0u;
     size_t used = base;
-    if (out_bytes >= kOrderMinOutBytes && room >= max_pages(n, out_bytes)) {
+    // The schedule is built when the batch can have more pages than the decode kernel has wavefronts (every page is at least 32 KiB) and the
+    // workspace has room for it; the kernels use it as it is from kOrderMinOutBytes of 64 KiB pages on, and folded for a batch of more pages than
+    // wavefronts and at most twice as many (schedule_mode in brotlig_kernels.h; enqueue() fills in the wavefront count).
+    Grids g;
+    const uint64_t waves = grid_sizes(&g) == BROTLIG_OK ? (uint64_t)g.decode : 0u;
+    if ((out_bytes >= kOrderMinOutBytes || (waves != 0u && out_bytes / kMinPageSize > waves)) && room >= max_pages(n, out_bytes)) {
         a.order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_ws) + base);
         a.order_cap = (uint32_t)max_pages(n, out_bytes);
+        a.order_from_k = (uint16_t)(kOrderMinOutBytes >> 26);            // 768 MiB of 64 KiB pages = 12 x 1 024 pages
         used = base + 4u * max_pages(n, out_bytes);
     }
 #ifdef BROTLIG_WITH_SPLIT
@@ -219,10 +225,23 @@ void launch_prepare(const DecodeArgs& a, hipStream_t s)
 }
 
 // prepare (page counts -> prefix) then the persistent page-decode kernel; k0/k1 bracket the latter
-BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
+// wavefronts of brotlig_decode_kernel for this batch: a batch that cannot hold more pages than that needs no more (every page is at least
+// 32 KiB of the caller's output region); the diagnostics knob pins it
+unsigned classic_grid(const DecodeArgs& a, const Grids& g)
+{
+    const uint64_t bound = max_pages(a.num_streams, a.out_bytes);
+    unsigned grid = bound < (uint64_t)g.decode ? (unsigned)(bound ? bound : 1u) : (unsigned)g.decode;
+    const uint32_t forced = g_debug_grid.load();
+    if (forced) grid = forced < (unsigned)g.decode ? forced : (unsigned)g.decode;
+    return grid;
+}
+
+BROTLIG_ERROR enqueue(const DecodeArgs& args, hipStream_t s, hipEvent_t k0, hipEvent_t k1)
 {
     Grids g;
     if (BROTLIG_ERROR e = grid_sizes(&g)) return e;
+    DecodeArgs a = args;
+    a.decode_waves = (uint16_t)std::min(classic_grid(a, g), 65535u);    // (schedule_mode: a batch of up to twice as many pages takes them folded)
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), s));
     launch_prepare(a, s);
     if (a.order) {                                                      // page schedule: count, then scatter
@@ -263,10 +282,7 @@ BROTLIG_ERROR enqueue(const DecodeArgs& a, hipStream_t s, hipEvent_t k0, hipEven
             hipLaunchKernelGGL(brotlig_decode_duo_kernel, dim3(grid), dim3(128), 0, s, b);
         }
         if (classic) {
-            // a batch that cannot hold more pages than that needs no more wavefronts (every page is at least 32 KiB of the caller's output region)
-            unsigned grid = bound < (uint64_t)g.decode ? (unsigned)(bound ? bound : 1u) : (unsigned)g.decode;
-            if (forced) grid = forced < (unsigned)g.decode ? forced : (unsigned)g.decode;
-            hipLaunchKernelGGL(brotlig_decode_kernel, dim3(grid), dim3(64), 0, s, b);
+            hipLaunchKernelGGL(brotlig_decode_kernel, dim3(classic_grid(a, g)), dim3(64), 0, s, b);
         }
     }
     if (k1) HIP_OK(hipEventRecord(k1, s));
@@ -696,6 +712,7 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     HIP_OK(hipMemset(prof.p, 0, prof_words * sizeof(unsigned long long)));
     DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, ws_bytes, d_scratch);
     a.prof = static_cast<unsigned long long*>(prof.p);
+    a.decode_waves = (uint16_t)std::min(g.decode, 65535);
     HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), nullptr));
     launch_prepare(a, nullptr);
     if (a.order) {

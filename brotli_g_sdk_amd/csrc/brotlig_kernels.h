@@ -81,6 +81,8 @@ struct DecodeArgs {
     uint8_t* out;       uint64_t out_bytes;
     uint8_t* scratch;   // conditioned-space staging for preconditioned streams (same layout as out)
     const StreamDesc* streams; uint32_t num_streams;
+    uint16_t decode_waves;  // the order kernels' business (schedule_mode below; in what was padding: the page kernels' code does not move): the wavefronts
+    uint16_t order_from_k;  // of brotlig_decode_kernel for this batch (0: unknown), and from how many pages on (in units of 1 024) a batch gets the schedule proper
     uint32_t* page_base;    // [num_streams + 1] exclusive prefix of page counts
     uint32_t* work_counter; // [1] next global page index
     uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams, [3] pairing policy, [5] de-conditioning super-tiles of the
@@ -916,6 +918,26 @@ __device__ __forceinline__ void flag_bad_page(const DecodeArgs& a, uint32_t s)
 {
     atomicOr(a.status, kStatusBadPage);
     atomicOr(&a.dc[s].status, kStatusBadPage);
+}
+
+// What the order kernels write into the page schedule (DecodeArgs::order, there whenever the workspace has room for it) for a batch of
+// `total` pages -- the page kernel takes order[k] for its k-th request whatever it holds:
+//   0  page order (order[k] = k): the batch is too small for anything else to pay;
+//   1  the schedule proper: bucket by bucket, dense pages first, similar pages side by side (large batches: every half-wave decodes many
+//      pages, and two pages that share a wavefront cost the slower one's time in every phase of a round);
+//   2  the schedule FOLDED (late round 5): the batch has more pages than the launch has wavefronts and at most twice as many -- every
+//      half-wave gets one page at most, all at the start, and what the launch takes is its most loaded wavefront.  Even requests are answered
+//      from the front of the schedule and odd ones from its back: the two halves of a wavefront ask together, so the densest page meets the
+//      lightest, the second densest the second lightest ...  (4 096 textures with mip chains -- 6 827 pages of 64, 44 and 23 KiB -- in page
+//      order: wavefronts with two full pages while others hold none; profiles/experiments/r05_many_textures.md.)
+#ifndef BROTLIG_TUNE_FOLD
+#define BROTLIG_TUNE_FOLD 1
+#endif
+__device__ __forceinline__ uint32_t schedule_mode(const DecodeArgs& a, uint32_t total)
+{
+    const uint32_t waves = a.decode_waves;
+    if (BROTLIG_TUNE_FOLD && waves != 0u && total > waves && total - waves <= waves) return 2u;
+    return total >= 1024u * a.order_from_k ? 1u : 0u;
 }
 
 // The job of global page index `g` (meaningful when `ok`): stream lookup, page table walk
@@ -2850,6 +2872,11 @@ __global__ void __launch_bounds__(64) brotlig_order_scatter_kernel(DecodeArgs a)
     __shared__ uint32_t cnt[kBuckets], base[kBuckets], start[kBuckets];
     const uint32_t lane = threadIdx.x, total = a.page_base[a.num_streams];
     if (a.order == nullptr || total > a.order_cap) return;
+    const uint32_t mode = schedule_mode(a, total);
+    if (mode == 0u) {                                                   // page order
+        for (uint32_t g = blockIdx.x * 64u + lane; g < total; g += gridDim.x * 64u) a.order[g] = g;
+        return;
+    }
     {   // where each bucket starts in the schedule: exclusive prefix of the histogram, one bucket per lane
         const uint32_t h = lane < kBuckets ? a.status[kOrderHist + lane] : 0u;
         const uint32_t incl_half = wave::half_scan_incl(h);
@@ -2872,7 +2899,11 @@ __global__ void __launch_bounds__(64) brotlig_order_scatter_kernel(DecodeArgs a)
         wave::sync();
         if (lane < kBuckets) base[lane] = cnt[lane] ? atomicAdd(a.status + kOrderCursor + lane, cnt[lane]) : 0u;
         wave::sync();
-        if (g < total) a.order[start[b] + base[b] + rank] = g;
+        if (g < total) {
+            const uint32_t p = start[b] + base[b] + rank;               // place in the schedule proper
+            // folded: the front half of the schedule answers the even requests, the back half -- from the end -- the odd ones
+            a.order[mode == 2u ? (p <= (total - 1u) >> 1 ? 2u * p : 2u * (total - 1u - p) + 1u) : p] = g;
+        }
         wave::sync();
     }
 }

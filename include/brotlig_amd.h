@@ -107,7 +107,8 @@ typedef struct BrotligStreamDesc {
 size_t BrotligDecodeWorkspaceSize(uint32_t num_streams);
 /* Workspace size that also holds the page schedule for `out_bytes` of output (one word per page): with
  * it, batches of 768 MiB and more are decoded bucket by bucket, similar pages side by side (about 12 %
- * faster on mixed data).  BrotligDecodeWorkspaceSize is the minimum; anything in between works. */
+ * faster on mixed data), and batches of between one and two pages per wavefront of the page kernel
+ * (256 .. 512 MiB of 64 KiB pages on an MI355X) densest page next to lightest.  BrotligDecodeWorkspaceSize is the minimum; anything in between works. */
 size_t BrotligDecodeWorkspaceSizeFor(uint32_t num_streams, uint64_t out_bytes);
 
 /* Enqueue the decode of `num_streams` streams.

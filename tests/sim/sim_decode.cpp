@@ -14,6 +14,7 @@ using namespace brotlig;
 
 static uint32_t g_last_policy = 0;
 static int g_use_order = 1;      // page schedule on (the GPU host code only uses it for large batches)
+static uint16_t g_order_from_k = 0;   // DecodeArgs::order_from_k: 0 = every batch gets the schedule proper (the host: from 12 x 1 024 pages on)
 static void prepare_body(void* p) { brotlig_prepare_kernel(*(DecodeArgs*)p); }
 static void prepare_finish_body(void* p) { brotlig_prepare_finish_kernel(*(DecodeArgs*)p); }
 // the host's launch_prepare (csrc/brotlig_hip.hip): one workgroup per 64 streams, the second kernel for more than 64 streams
@@ -69,6 +70,8 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     std::vector<uint32_t> order(g_use_order ? (size_t)(out_bytes / 32768 + num_streams + 1) : 0);
     if (g_use_order) { a.order = order.data(); a.order_cap = (uint32_t)order.size(); }
     const int decode_grid = grid ? grid : 4;
+    a.order_from_k = g_order_from_k;
+    a.decode_waves = (uint16_t)decode_grid;     // (the schedule proper for every batch, order_from_k = 0 -- except the batches schedule_mode folds)
     std::vector<uint16_t> far_syms((size_t)decode_grid * 2u * kFarSymStride, 0xFFFFu);     // stale garbage between pages, as on the device
     a.far_syms = far_syms.data();
     run_prepare(a);
@@ -143,6 +146,7 @@ extern "C" int sim_entropy_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* 
 
 extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word 3: pairing policy chosen by the prepare kernel
 extern "C" void sim_set_order(int on) { g_use_order = on; }
+extern "C" void sim_set_order_from_k(uint32_t k) { g_order_from_k = (uint16_t)k; }
 extern "C" void sim_selftest(uint32_t* out) { sim::run_grid(1, selftest_body, out); }
 extern "C" uint64_t sim_collectives() { return sim::g_waves[0].n_collectives; }
 

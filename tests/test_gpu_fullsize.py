@@ -86,6 +86,40 @@ def test_one_stream_of_65535_pages(api):
         assert hashlib.sha256(out[k * len(data):(k + 1) * len(data)].tobytes()).digest() == want, k
 
 
+def test_batch_between_one_and_two_pages_per_wavefront_is_taken_folded(api):
+    """A batch with more pages than the page kernel has wavefronts and at most twice as many (here 6 400 pages, 400 MiB; the launch has 16
+    wavefronts per compute unit) gives every half-wave one page at most, all at the start: the requests are answered from both ends of the page
+    schedule in turn, so that the densest page shares its wavefront with the lightest (schedule_mode 2 in brotlig_kernels.h, late round 5).
+    Three plain streams of 2 000 pages (250 distinct, tiled) and 200 BC textures with mip chains (a full page and a short one each), every
+    byte compared."""
+    import torch
+    from brotli_g_sdk_amd import datagen as D, encoder as E
+    B = _bench()
+    streams, expected = B.build_streams("mixed", [0, 1, 2], 2000, 250)
+    sizes = [2000 * 65536] * 3
+    texs = []
+    for k in range(200):
+        fmt = (3, 5)[k & 1]
+        if k < 8:
+            tex = D.bc_texture(fmt, 64, 64, seed=900 + k, num_mips=7)
+            st = E.encode(tex, precondition=dict(format=fmt, width_blocks=64, height_blocks=64, num_mips=7, swizzle=1, delta=1))
+            texs.append((st, tex))
+        st, tex = texs[k % 8]
+        streams.append(st); sizes.append(len(tex))
+    dec = api.BatchDecoder(streams, out_sizes=sizes)
+    assert 4096 < sum((n + 65535) // 65536 for n in sizes) <= 8192
+    dec.poison_output()
+    dec.decode()
+    torch.cuda.synchronize()
+    assert dec.stream_status() == (0, [0] * len(streams))
+    for k in range(3):
+        exp = torch.from_numpy(expected[k]).to(dec.device)
+        got = dec.d_out[dec.out_offs[k]:dec.out_offs[k] + dec.sizes[k]].view(8, -1)
+        assert bool((got == exp.unsqueeze(0)).all()), k
+    for k in range(200):
+        assert np.array_equal(dec.output(3 + k), texs[k % 8][1]), k
+
+
 def test_config4_bc3_4gib_full_size(api):
     """configs[3]: 256 BC3 textures of 1024 x 1024 blocks (16 MiB, 256 pages each), swizzle + delta; 8 distinct
     textures repeated as whole streams ("BC7-style" is realised as BC3: the reference has BC1-BC5 only)."""

@@ -351,6 +351,25 @@ def test_sim_decondition_large_textures_go_to_gangs_of_256(sim, grid):
         assert np.array_equal(outs[k], want[k]), k
 
 
+@pytest.mark.parametrize("grid,what", [(2, "page order"), (4, "folded"), (6, "folded"), (7, "one page per wavefront")])
+def test_sim_schedule_modes_of_a_small_batch(sim, grid, what):
+    """What the order kernels write for a batch below the schedule's own threshold (the host: 12 288 pages; here raised above the batch
+    through sim_set_order_from_k): page order -- unless the batch has more pages than the page kernel has wavefronts and at most twice as
+    many, then the schedule FOLDED, front and back in turn, so that the two halves of a wavefront get the densest and the lightest page
+    (schedule_mode in brotlig_kernels.h, late round 5).  Seven pages of very different cost (text, runs, stored, a short last page) on 2, 4,
+    6 and 7 wavefronts: the same bytes."""
+    datas = [D.text(65536, 31), D.runs(65536, 32), D.random_bytes(65536, 33), D.records(65536 + 9000, 34), D.samples16(65536, 35), np.zeros(700, np.uint8)]
+    streams = [E.encode(d) for d in datas]
+    sim.sim_set_order_from_k(60)
+    try:
+        outs, status = run_batch(sim, streams, [len(d) for d in datas], grid=grid)
+    finally:
+        sim.sim_set_order_from_k(0)
+    assert status == 0
+    for o, d in zip(outs, datas):
+        assert np.array_equal(o, d), what
+
+
 def test_sim_host_rule_exactly_one_kernel_decodes(sim):
     """The host launches BOTH page kernels when the output size leaves the page count open, and the device decides (DecodeArgs::duo_limit
     against the page count the prepare kernel found); it skips the policy kernel when no two pages can meet (csrc/brotlig_hip.hip enqueue()).
