@@ -186,12 +186,15 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
     const size_t base = workspace_bytes(n);
     const uint64_t room = ws_bytes > base ? (ws_bytes - base) / 4u : 0u;
     size_t used = base;
-    // The schedule is built when the batch can have more pages than the decode kernel has wavefronts (every page is at least 32 KiB) and the
-    // workspace has room for it; the kernels use it as it is from kOrderMinOutBytes of 64 KiB pages on, and folded for a batch of more pages than
-    // wavefronts and at most twice as many (schedule_mode in brotlig_kernels.h; enqueue() fills in the wavefront count).
+    // The schedule is built for batches of kOrderMinOutBytes and more, and for smaller ones that have more pages than the decode kernel has
+    // wavefronts if their pages are the usual 64 KiB (the host knows the output size, not the page size: a batch that only MIGHT have that
+    // many pages -- BASELINE config 2 is 256 MiB in 4 096 pages -- does not pay two launches for a schedule that says "page order"), when the
+    // workspace has room for it.  What the order kernels write into it is schedule_mode's choice (brotlig_kernels.h; enqueue() fills in the
+    // wavefront count): the schedule proper from kOrderMinOutBytes of 64 KiB pages on, folded for a batch of more pages than wavefronts and
+    // at most twice as many, page order otherwise.
     Grids g;
     const uint64_t waves = grid_sizes(&g) == BROTLIG_OK ? (uint64_t)g.decode : 0u;
-    if ((out_bytes >= kOrderMinOutBytes || (waves != 0u && out_bytes / kMinPageSize > waves)) && room >= max_pages(n, out_bytes)) {
+    if ((out_bytes >= kOrderMinOutBytes || (waves != 0u && out_bytes / 65536u > waves)) && room >= max_pages(n, out_bytes)) {
         a.order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_ws) + base);
         a.order_cap = (uint32_t)max_pages(n, out_bytes);
         a.order_from_k = (uint16_t)(kOrderMinOutBytes >> 26);            // 768 MiB of 64 KiB pages = 12 x 1 024 pages
