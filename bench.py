@@ -151,8 +151,9 @@ def kernel_source_hash():
     """First 16 hex digits of the SHA-256 of the decode kernels' source: ties a profile to the build it measured."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h"):
-        h.update(open(os.path.join(ROOT, "brotli_g_sdk_amd", "csrc", name), "rb").read())
+    from brotli_g_sdk_amd import _build
+    for path in _build.kernel_headers():
+        h.update(open(path, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -42,8 +42,19 @@ def build_cpu(force=False):
 
 
 def hip_sources():
-    names = ["brotlig_hip.hip", "brotlig_streamer.hip", "brotlig_kernels.h", "brotlig_wave_ops.h", "brotlig_format.h", "brotlig_shard_plan.h", "brotlig_internal.h"]
-    return [os.path.join(CSRC, n) for n in names] + [os.path.join(ROOT, "include", "brotlig_amd.h")]
+    """The two translation units first, then every header of csrc/ they may include (the kernels are a set of per-stage headers under
+    brotlig_kernels.h)."""
+    import glob
+    units = [os.path.join(CSRC, n) for n in ("brotlig_hip.hip", "brotlig_streamer.hip")]
+    headers = sorted(h for h in glob.glob(os.path.join(CSRC, "brotlig_*.h")) if not h.endswith("brotlig_encoder.h"))
+    return units + headers + [os.path.join(ROOT, "include", "brotlig_amd.h")]
+
+
+def kernel_headers():
+    """The headers the kernels are made of (hashed by bench.py, watched by the simulator build of tests/test_sim_decode.py)."""
+    import glob
+    skip = ("brotlig_encoder.h", "brotlig_internal.h", "brotlig_shard_plan.h")
+    return sorted(h for h in glob.glob(os.path.join(CSRC, "brotlig_*.h")) if not h.endswith(skip))
 
 
 def build_hip(force=False):

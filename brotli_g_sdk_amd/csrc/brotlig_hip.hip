@@ -23,9 +23,6 @@
 #include "brotlig_kernels.h"
 #include "brotlig_shard_plan.h"
 #include "brotlig_internal.h"
-#ifdef BROTLIG_WITH_SPLIT     // experiment builds only (profiles/experiments/r03_split_path.md, built with -I profiles/experiments/split_path): not part of the product
-#include "brotlig_split_kernels.h"
-#endif
 
 using namespace brotlig;
 
@@ -52,19 +49,6 @@ constexpr uint32_t kMaxDecodeGrid = 8192;
 constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
 size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
 size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
-// Split path (profiles/experiments/split_path/brotlig_split_kernels.h): an A/B experiment of round 3, compiled in with -DBROTLIG_WITH_SPLIT only and then
-// switched on with BROTLIG_SPLIT=1|2.  Per page one slot of (cap + 1) command words and a literal array of a page plus
-// slack, and two header words.
-#ifdef BROTLIG_WITH_SPLIT
-int split_mode() { static const int m = [] { const char* e = getenv("BROTLIG_SPLIT"); return e ? atoi(e) : 0; }(); return m; }     // 1: LDS-window assembly, 2: in-place assembly
-bool split_enabled() { return split_mode() != 0; }
-uint32_t split_cmd_cap() { static const uint32_t c = [] { const char* e = getenv("BROTLIG_SPLIT_CAP"); return e ? (uint32_t)atoi(e) : 16384u; }(); return c; }
-constexpr uint32_t kLitStride = kMaxPageSize + 64u;
-size_t split_slot_bytes() { return ((size_t)split_cmd_cap() + 1u) * 8u + kLitStride + 8u; }
-#else
-bool split_enabled() { return false; }
-size_t split_slot_bytes() { return 0; }
-#endif
 // every page is at least 32 KiB of output, and every stream's output region is whole pages
 uint64_t max_pages(uint32_t n, uint64_t out_bytes) { return out_bytes / kMinPageSize + n; }
 // Below this many pages the schedule is not worth its two extra launches (about two pages per half-wave).
@@ -74,9 +58,6 @@ constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
 // host threads driving different devices (or the same one) may arrive here concurrently.
 struct Grids {
     int decode = 0, decond = 1024, order = 1024, duo = 512;
-#ifdef BROTLIG_WITH_SPLIT
-    int entropy = 0, assemble = 0, assemble_global = 0, assemble_page = 0;
-#endif
 };
 // Diagnostics switches, read ONCE per process (never in the launch path): BROTLIG_WG_PER_CU pins the decode grid per compute unit
 // (profiles/tools/occ_probe.sh), BROTLIG_POLICY the pairing policy (policy_sweep.sh).  -1 = not set.
@@ -131,30 +112,6 @@ BROTLIG_ERROR grid_sizes(Grids* out)
         g.duo = cus * kDuoPerCu;
         g.order = cus * 4;
         g.decode = cus * per_cu < (int)kMaxDecodeGrid ? cus * per_cu : (int)kMaxDecodeGrid;
-#ifdef BROTLIG_WITH_SPLIT
-        auto grid_of = [&](const void* fn, const char* env, int* out) -> BROTLIG_ERROR {
-            int n = 0;
-            hipFuncAttributes a{};
-            HIP_OK(hipFuncGetAttributes(&a, fn));
-            HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 64, 0));
-            const int gr = (int)((a.sharedSizeBytes + 1279u) / 1280u);
-            if (gr > 0 && n > 128 / gr) n = 128 / gr;
-            if (const char* e = getenv(env)) n = atoi(e);
-            if (n < 1) n = 1;
-            *out = cus * n < (int)kMaxDecodeGrid ? cus * n : (int)kMaxDecodeGrid;
-            return BROTLIG_OK;
-        };
-        if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_entropy_kernel), "BROTLIG_E_PER_CU", &g.entropy)) return e;
-        if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_kernel), "BROTLIG_L_PER_CU", &g.assemble)) return e;
-        if (BROTLIG_ERROR e = grid_of(reinterpret_cast<const void*>(brotlig_assemble_global_kernel), "BROTLIG_G_PER_CU", &g.assemble_global)) return e;
-        {   // page-in-LDS assembly: workgroups of kPageWaves wavefronts, 65 KiB of LDS each
-            int n = 0;
-            HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, brotlig_assemble_page_kernel, 64 * (int)kPageWaves, 0));
-            if (const char* e = getenv("BROTLIG_P_PER_CU")) n = atoi(e);
-            if (n < 1) n = 1;
-            g.assemble_page = cus * n;
-        }
-#endif
     }
     *out = g;
     return BROTLIG_OK;
@@ -200,20 +157,6 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
         a.order_from_k = (uint16_t)(kOrderMinOutBytes >> 26);            // 768 MiB of 64 KiB pages = 12 x 1 024 pages
         used = base + 4u * max_pages(n, out_bytes);
     }
-#ifdef BROTLIG_WITH_SPLIT
-    a.work_counter2 = ws + 4;
-    if (split_enabled()) {                                              // slots behind the schedule, if the workspace has them
-        const uint64_t pages = max_pages(n, out_bytes);
-        used = (used + 255u) & ~(size_t)255u;
-        if (ws_bytes >= used + pages * split_slot_bytes()) {
-            uint8_t* p = static_cast<uint8_t*>(d_ws) + used;
-            a.cmd_cap = split_cmd_cap(); a.lit_stride = kLitStride;
-            a.cmds = reinterpret_cast<uint64_t*>(p); p += pages * ((size_t)a.cmd_cap + 1u) * 8u;
-            a.lits = p; p += pages * (size_t)kLitStride;
-            a.slot_hdr = reinterpret_cast<uint32_t*>(p);
-        }
-    }
-#endif
     (void)used;
     return a;
 }
@@ -258,14 +201,6 @@ BROTLIG_ERROR enqueue(const DecodeArgs& args, hipStream_t s, hipEvent_t k0, hipE
     if (diag_policy() >= 0)                             // diagnostics: pin the pairing policy (quarters of a page a free half waits)
         HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), diag_policy(), 1, s));
     if (k0) HIP_OK(hipEventRecord(k0, s));
-#ifdef BROTLIG_WITH_SPLIT
-    if (a.cmds != nullptr) {                                            // split path: entropy decode, then assembly
-        hipLaunchKernelGGL(brotlig_entropy_kernel, dim3(g.entropy), dim3(64), 0, s, a);
-        if (split_mode() == 3) hipLaunchKernelGGL(brotlig_assemble_page_kernel, dim3(g.assemble_page), dim3(64 * kPageWaves), 0, s, a);
-        else if (split_mode() == 2) hipLaunchKernelGGL(brotlig_assemble_global_kernel, dim3(g.assemble_global), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL(brotlig_assemble_kernel, dim3(g.assemble), dim3(64), 0, s, a);
-    } else
-#endif
     {   // a batch that cannot hold more pages than that needs no more wavefronts (every page is at least 32 KiB of the caller's output
         // region): a single asset launches a handful of workgroups instead of 4 096.  (The kernel itself sends home every wavefront beyond
         // the batch's page count before it touches the page counter -- that is what takes 45 us off a single page; round 4.)
@@ -327,7 +262,6 @@ extern "C" size_t BrotligDecodeWorkspaceSize(uint32_t num_streams) { return work
 extern "C" size_t BrotligDecodeWorkspaceSizeFor(uint32_t num_streams, uint64_t out_bytes)
 {
     size_t b = workspace_bytes(num_streams) + (size_t)(4u * max_pages(num_streams, out_bytes));
-    if (split_enabled()) b = ((b + 255u) & ~(size_t)255u) + (size_t)max_pages(num_streams, out_bytes) * split_slot_bytes();
     return b;
 }
 

@@ -73,7 +73,10 @@ def _decode_mode_from_env():
 #   pair  -- brotlig_decode_kernel forced onto ONE wavefront: decode_pages<.., false>, two pages per wavefront, one per 32-lane half -- the
 #            form every large batch (the benchmark) runs.  A batch needs at least two pages for it, so single-stream cases go through
 #            BatchDecoder with a companion stream (helpers: decode_all_forms below).
-KERNEL_FORMS = (("rule", 0, 0), ("solo", 1, 0), ("pair", 1, 1))
+#   pair3 -- the same on THREE wavefronts (round 6): the cases also meet the atomic hand-out of pages between wavefronts,
+#            the page schedule's job records taken out of order, and a neighbour wavefront's overflow slots in the workspace.  The batches of
+#            this form hold at least six pages, so that every one of the three wavefronts runs the two-page form.
+KERNEL_FORMS = (("rule", 0, 0), ("solo", 1, 0), ("pair", 1, 1), ("pair3", 1, 3))
 
 
 @pytest.fixture(params=KERNEL_FORMS, ids=[f[0] for f in KERNEL_FORMS])

@@ -40,18 +40,26 @@ def decode_in_form(api, form, stream, out_size=None):
     """The decoded bytes of `stream` under the kernel form the `kernel_form` fixture has pinned (tests/conftest.py).  `rule` and `solo` go
     through the host-pointer entry (DecodeGPU), like a caller of the reference; `pair` -- two pages per wavefront, the form of every large
     batch -- needs more than one page in the launch: the stream twice, a companion of another kind between them, one wavefront for all."""
-    if form != "pair":
+    if form not in ("pair", "pair3"):
         out, ms = api.DecodeGPU(stream, output_size=out_size)
         assert ms > 0.0
         return out
     comp_d, comp_s = _companion()
     n = int(api.DecompressedSize(stream)) if out_size is None else int(out_size)
-    dec = api.BatchDecoder([stream, comp_s, stream], out_sizes=[n, len(comp_d), n])
+    # pair3: three wavefronts, at least seven pages (the companion has two) -- all three run the two-page form and hand pages out between them
+    copies = 3 if form == "pair3" else 2
+    streams, sizes = [], []
+    for k in range(copies):
+        streams += [stream] + ([comp_s] if k + 1 < copies else [])
+        sizes += [n] + ([len(comp_d)] if k + 1 < copies else [])
+    dec = api.BatchDecoder(streams, out_sizes=sizes)
     dec.poison_output()
     dec.decode()
-    assert np.array_equal(dec.output(1), comp_d), "the companion stream"
-    first, second = dec.output(0), dec.output(2)
-    assert np.array_equal(first, second), "the same stream twice in one launch"
+    for k in range(copies - 1):
+        assert np.array_equal(dec.output(2 * k + 1), comp_d), "the companion stream"
+    first = dec.output(0)
+    for k in range(1, copies):
+        assert np.array_equal(first, dec.output(2 * k)), "the same stream several times in one launch"
     return first
 
 
@@ -130,7 +138,7 @@ def test_golden_fixtures_on_gpu(api, kernel_form):
     index = json.load(open(os.path.join(GOLDEN, "index.json")))
     names = sorted(index)
     streams = [np.fromfile(os.path.join(GOLDEN, name + ".brotlig"), dtype=np.uint8) for name in names]
-    if kernel_form == "pair":       # all fixtures in ONE launch on one wavefront: pages of unrelated fixtures side by side in its two halves
+    if kernel_form in ("pair", "pair3"):       # all fixtures in ONE launch on one (three) wavefront(s): pages of unrelated fixtures side by side in the halves
         dec = api.BatchDecoder(streams, out_sizes=[index[n]["size"] for n in names])
         dec.poison_output()
         dec.decode()

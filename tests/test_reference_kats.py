@@ -33,7 +33,7 @@ def test_cmd_lut_all_rows(oracle):
 
 def test_kernel_length_tables_match_reference_lut():
     """The 48-entry base|extra table compiled into the kernels reproduces the LUT's columns."""
-    src = open(os.path.join(os.path.dirname(__file__), "..", "brotli_g_sdk_amd", "csrc", "brotlig_kernels.h")).read()
+    src = open(os.path.join(os.path.dirname(__file__), "..", "brotli_g_sdk_amd", "csrc", "brotlig_kernel_common.h")).read()
     tab = src[src.index("kLenCodeTab[48]"):]
     tab = tab[:tab.index("};")]
     ents = [(int(b), int(e)) for b, e in re.findall(r"(\d+)u \| (\d+)u << 16", tab)]

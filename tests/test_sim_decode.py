@@ -9,6 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
+from brotli_g_sdk_amd import _build
 from brotli_g_sdk_amd import datagen as D
 from brotli_g_sdk_amd import encoder as E
 from cases import plain_cases, precon_cases, raw_stress_cases, symbol_overflow_cases
@@ -32,7 +33,7 @@ def build_sim(name, flags=(), split=False):
     so = os.path.join(SIM_DIR, name)
     srcs = [os.path.join(SIM_DIR, f) for f in ("sim_decode.cpp", "sim_runtime.cpp")]
     deps = srcs + [os.path.join(SIM_DIR, f) for f in ("sim_runtime.h", "brotlig_wave_ops.h")] + \
-        [os.path.join(CSRC, f) for f in ("brotlig_kernels.h", "brotlig_format.h")]
+        _build.kernel_headers()
     if split:       # the two-kernel experiment of round 3 lives with the other experiments, outside the package (tests/test_sim_split.py)
         deps.append(os.path.join(SPLIT_DIR, "brotlig_split_kernels.h"))
         flags = list(flags) + ["-DBROTLIG_WITH_SPLIT", "-I", SPLIT_DIR]
