@@ -41,7 +41,7 @@ class DeviceBatch(ctypes.Structure):
                 ("kernel_ms", ctypes.c_double), ("wall_ms", ctypes.c_double)]
 
 
-ABI_VERSION = 3         # BROTLIG_AMD_ABI_VERSION: the batch entry points carry it in their symbol names
+ABI_VERSION = 4         # BROTLIG_AMD_ABI_VERSION: the batch entry points carry it in their symbol names
 _VERSIONED = ("BrotligDecodeWorkspaceSize", "BrotligDecodeWorkspaceSizeFor", "BrotligDecodeBatchDevice", "BrotligDecodeBatchStatus",
               "BrotligDecodeBatchTimed", "BrotligDecodePhaseProfile", "BrotligDecodeBatchMultiDevice")
 
@@ -50,13 +50,14 @@ _lib = None
 
 class _Lib:
     """The shared library with the header's symbol-version macros applied: L.BrotligDecodeBatchDevice is the symbol
-    BrotligDecodeBatchDevice_v3, as it is for a C caller that includes brotlig_amd.h."""
+    BrotligDecodeBatchDevice_v4, as it is for a C caller that includes brotlig_amd.h."""
 
-    def __init__(self, cdll):
+    def __init__(self, cdll, version=ABI_VERSION):
         object.__setattr__(self, "_cdll", cdll)
+        object.__setattr__(self, "_version", version)
 
     def __getattr__(self, name):
-        return getattr(self._cdll, f"{name}_v{ABI_VERSION}" if name in _VERSIONED else name)
+        return getattr(self._cdll, f"{name}_v{self._version}" if name in _VERSIONED else name)
 
 
 def lib():
@@ -64,10 +65,14 @@ def lib():
     global _lib
     if _lib is None:
         import torch  # noqa: F401  -- torch's copy of the HIP runtime must be the one in the process: loaded after this library it sees no device
-        L = _Lib(ctypes.CDLL(_build.build_hip()))
-        L.BrotligAbiVersion.restype = ctypes.c_uint32
-        if L.BrotligAbiVersion() != ABI_VERSION:
-            raise RuntimeError("libbrotlig_hip.so has ABI version %d, this mirror expects %d" % (L.BrotligAbiVersion(), ABI_VERSION))
+        cdll = ctypes.CDLL(_build.build_hip())
+        cdll.BrotligAbiVersion.restype = ctypes.c_uint32
+        found = int(cdll.BrotligAbiVersion())
+        # only an A/B build of an OLDER source loaded through BROTLIG_HIP_SO (profiles/tools/ab_run.py) may carry another version: the calls
+        # this mirror makes have had the same arguments since version 3, and every workspace size is asked of the loaded library
+        if found != ABI_VERSION and not (os.environ.get("BROTLIG_HIP_SO") and found == 3):
+            raise RuntimeError("libbrotlig_hip.so has ABI version %d, this mirror expects %d" % (found, ABI_VERSION))
+        L = _Lib(cdll, found)
         L.BrotligShardPlan.restype = ctypes.c_int
         L.BrotligShardPlan.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
         L.BrotligDecodeBatchMultiDevice.restype = ctypes.c_int
@@ -398,6 +403,18 @@ class BatchDecoder:
             if rc != BROTLIG_OK:
                 raise BrotligError(rc, "BrotligDecodePhaseProfile")
             return out[len(self.PHASES):].reshape(grid, 2)
+
+    def schedule_times(self, tickets=4096):
+        """(came, ticket, phase open, done) ticks of a 100 MHz counter for the first `tickets` workgroups -- by ticket -- of the schedule kernel of
+        one launch (diagnostics, round 6: where the one kernel in front of the page decode spends its time)."""
+        with self.torch.cuda.device(self.device):
+            self.torch.cuda.synchronize()
+            grid = int(lib().BrotligKernelGridSize())
+            out = np.zeros(len(self.PHASES) + 2 * grid + 4 * tickets, dtype=np.uint64)
+            rc = lib().BrotligDecodePhaseProfile(*self._args(None)[:9], out.ctypes.data, len(out))
+            if rc != BROTLIG_OK:
+                raise BrotligError(rc, "BrotligDecodePhaseProfile")
+            return out[len(self.PHASES) + 2 * grid:].reshape(tickets, 4)
 
     def output(self, i):
         """Decompressed bytes of stream i as a host uint8 array."""

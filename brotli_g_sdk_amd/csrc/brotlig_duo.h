@@ -62,7 +62,7 @@ __device__ inline void duo_producer(DuoLds& D, const DecodeArgs& a)
     const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist, far_syms};
     const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit, nullptr};
 
-    PageJob job = fetch_job(a, nullptr, 0u, false);
+    PageJob job = no_job(a);
     bool live = false, finished = lane >= 32u, bad = false;
     BitReader br;
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
@@ -217,7 +217,7 @@ __device__ inline void duo_consumer(DuoLds& D, const DecodeArgs& a)
     PhaseClock<false> clk;
     const uint32_t lane = wave::lane_id(), sl = lane & 31u;
     const bool lower = lane < 32u;
-    PageJob job = fetch_job(a, nullptr, 0u, false);
+    PageJob job = no_job(a);
     OutView view{D.win, 0u};
     uint32_t out_pos = 0, flushed = 0;
     uint32_t k = 0;                                                     // steps consumed so far

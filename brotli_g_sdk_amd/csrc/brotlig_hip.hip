@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <random>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -34,11 +35,12 @@ static_assert(sizeof(BrotligStreamDesc) == sizeof(StreamDesc), "descriptor layou
     fprintf(stderr, "brotlig_hip: %s failed: %s\n", #expr, hipGetErrorString(_e)); return BROTLIG_ERROR_GENERIC; } } while (0)
 
 // Device workspace (the reference's `meta` buffer): word 0 status, word 1 page counter, word 2
-// preconditioned-stream count, word 3 pairing policy, words 8..135 scheduling buckets, words 192..
-// page_base[num_streams + 1], then (1 KiB aligned) one DcTable per stream, then -- if the caller's
-// workspace has the room -- the page schedule (one word per page).
+// preconditioned-stream count, word 3 pairing policy, words 8..135 scheduling buckets, words 160..175 the schedule kernel's tickets and
+// phase counters, words 192.. page_base[num_streams + 1], then (1 KiB aligned) one DcTable per stream, then the per-wavefront symbol
+// slots, then -- if the caller's workspace has the room -- the page schedule (one 32-byte job record per page).
 constexpr size_t kWsHeaderWords = 192;
-static_assert(kWsHeaderWords >= kStatusWords, "the status words of the kernels (brotlig_kernels.h)");
+constexpr size_t kWsSyncAt = 160;        // the schedule kernel's own words: a 128-byte line of their own (the workgroups that wait look at it; the histogram's atomics go elsewhere)
+static_assert(kWsSyncAt >= kStatusWords && kWsSyncAt % 32u == 0u && kWsHeaderWords >= kWsSyncAt + kSyncWords, "the status words of the kernels, then the schedule kernel's");
 size_t dc_offset(uint32_t n) { return ((kWsHeaderWords + (size_t)n + 1u) * 4u + 1023u) & ~(size_t)1023u; }
 // per-half slots for the prefix-code symbols that overflow the LDS arrays, for every workgroup of the largest decode grid
 // (8192 workgroups x 2 halves x kFarSymStride uint16 = 30 MiB: the size brotlig_amd.h documents for the workspace)
@@ -49,15 +51,27 @@ constexpr uint32_t kMaxDecodeGrid = 8192;
 constexpr size_t kFarSymBytes = (size_t)kMaxDecodeGrid * 2u * kFarSymStride * sizeof(uint16_t);
 size_t far_syms_offset(uint32_t n) { return (dc_offset(n) + (size_t)n * sizeof(DcTable) + 255u) & ~(size_t)255u; }
 size_t workspace_bytes(uint32_t n) { return far_syms_offset(n) + kFarSymBytes; }
+size_t jobs_offset(uint32_t n) { return (workspace_bytes(n) + 255u) & ~(size_t)255u; }      // the page schedule, behind everything a batch must have
 // every page is at least 32 KiB of output, and every stream's output region is whole pages
 uint64_t max_pages(uint32_t n, uint64_t out_bytes) { return out_bytes / kMinPageSize + n; }
-// Below this many pages the schedule is not worth its two extra launches (about two pages per half-wave).
+// From this much output on (of 64 KiB pages: about two pages per half-wave) a batch gets the schedule proper; below it, page order or the folded schedule.
 constexpr uint64_t kOrderMinOutBytes = 768ull << 20;
+// every launch of the process carries another 40-bit tag (DecodeArgs::launch_tag, brotlig_schedule.h): a counter from a random start
+uint64_t next_launch_tag()
+{
+    static std::atomic<uint64_t> counter{[] {
+        std::random_device rd;
+        return ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+    }()};
+    uint64_t t;
+    do { t = counter.fetch_add(1) & ((1ull << 40) - 1u); } while (t == 0u);
+    return t;
+}
 
 // Launch geometry per device (CU count x occupancy of the decode kernel), looked up once per device;
 // host threads driving different devices (or the same one) may arrive here concurrently.
 struct Grids {
-    int decode = 0, decond = 1024, order = 1024, duo = 512;
+    int decode = 0, decond = 1024, sched = 256, duo = 512;
 };
 // Diagnostics switches, read ONCE per process (never in the launch path): BROTLIG_WG_PER_CU pins the decode grid per compute unit
 // (profiles/tools/occ_probe.sh), BROTLIG_POLICY the pairing policy (policy_sweep.sh).  -1 = not set.
@@ -108,9 +122,12 @@ BROTLIG_ERROR grid_sizes(Grids* out)
         if (granules > 0 && per_cu > 128 / granules) per_cu = 128 / granules;
         if (diag_wg_per_cu() > 0) per_cu = diag_wg_per_cu();
         if (per_cu < 1) per_cu = 1;
-        g.decond = cus * (env_int_once("BROTLIG_DC_PER_CU") > 0 ? env_int_once("BROTLIG_DC_PER_CU") : 32);   // wavefronts of the de-conditioning kernel (one per workgroup, 4 KiB of LDS each): 8 per SIMD
+        // wavefronts of the de-conditioning kernel (one per workgroup, 4 KiB of LDS each): 8 per SIMD.  (BROTLIG_DC_PER_CU: a diagnostics
+        // switch like the others -- honoured only in a process started with BROTLIG_ENABLE_DEBUG_KNOBS=1)
+        const int dc_per_cu = diag_knobs_enabled() ? env_int_once("BROTLIG_DC_PER_CU") : -1;
+        g.decond = cus * (dc_per_cu > 0 && dc_per_cu <= 64 ? dc_per_cu : 32);
         g.duo = cus * kDuoPerCu;
-        g.order = cus * 4;
+        g.sched = cus;                                                  // workgroups that walk the pages in the schedule kernel (count, scatter), kSchedThreads pages per step each
         g.decode = cus * per_cu < (int)kMaxDecodeGrid ? cus * per_cu : (int)kMaxDecodeGrid;
     }
     *out = g;
@@ -137,37 +154,41 @@ DecodeArgs make_args(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t 
     a.out = static_cast<uint8_t*>(d_out); a.out_bytes = out_bytes;
     a.scratch = static_cast<uint8_t*>(d_scratch);
     a.streams = reinterpret_cast<const StreamDesc*>(d_streams); a.num_streams = n;
-    a.status = ws; a.work_counter = ws + 1; a.page_base = ws + kWsHeaderWords;
+    a.status = ws; a.work_counter = ws + 1; a.sync = ws + kWsSyncAt; a.page_base = ws + kWsHeaderWords;
     a.dc = reinterpret_cast<DcTable*>(static_cast<uint8_t*>(d_ws) + dc_offset(n));
     a.far_syms = reinterpret_cast<uint16_t*>(static_cast<uint8_t*>(d_ws) + far_syms_offset(n));
-    const size_t base = workspace_bytes(n);
-    const uint64_t room = ws_bytes > base ? (ws_bytes - base) / 4u : 0u;
-    size_t used = base;
-    // The schedule is built for batches of kOrderMinOutBytes and more, and for smaller ones that have more pages than the decode kernel has
-    // wavefronts if their pages are the usual 64 KiB (the host knows the output size, not the page size: a batch that only MIGHT have that
-    // many pages -- BASELINE config 2 is 256 MiB in 4 096 pages -- does not pay two launches for a schedule that says "page order"), when the
-    // workspace has room for it.  What the order kernels write into it is schedule_mode's choice (brotlig_kernels.h; enqueue() fills in the
-    // wavefront count): the schedule proper from kOrderMinOutBytes of 64 KiB pages on, folded for a batch of more pages than wavefronts and
-    // at most twice as many, page order otherwise.
-    Grids g;
-    const uint64_t waves = grid_sizes(&g) == BROTLIG_OK ? (uint64_t)g.decode : 0u;
-    if ((out_bytes >= kOrderMinOutBytes || (waves != 0u && out_bytes / 65536u > waves)) && room >= max_pages(n, out_bytes)) {
-        a.order = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_ws) + base);
-        a.order_cap = (uint32_t)max_pages(n, out_bytes);
-        a.order_from_k = (uint16_t)(kOrderMinOutBytes >> 26);            // 768 MiB of 64 KiB pages = 12 x 1 024 pages
-        used = base + 4u * max_pages(n, out_bytes);
+    // The page schedule -- one job record per page the batch can hold -- whenever the workspace has the room (BrotligDecodeWorkspaceSizeFor).
+    // What the schedule kernel writes into it is schedule_mode's choice (brotlig_jobs.h; enqueue() fills in the wavefront count): the
+    // schedule proper from kOrderMinOutBytes of 64 KiB pages on, folded for a batch of more pages than wavefronts and at most twice as
+    // many, page order otherwise.  Without it (a workspace of the minimum size) the page kernels take pages in stream order and walk the
+    // page tables themselves.
+    const size_t base = jobs_offset(n);
+    const uint64_t cap = max_pages(n, out_bytes);
+    if (ws_bytes >= base && (ws_bytes - base) / sizeof(JobRecord) >= cap && cap <= 0xFFFFFFFFull) {
+        a.jobs = reinterpret_cast<JobRecord*>(static_cast<uint8_t*>(d_ws) + base);
+        a.jobs_cap = (uint32_t)cap;
     }
-    (void)used;
+    a.order_from_k = (uint16_t)(kOrderMinOutBytes >> 26);                // 768 MiB of 64 KiB pages = 12 x 1 024 pages
     return a;
 }
 
-// Stream headers -> page counts -> exclusive prefix: one workgroup per 64 streams, and for more than 64 streams a second launch that adds
-// what lies before each workgroup's streams (brotlig_prepare_finish_kernel).
-void launch_prepare(const DecodeArgs& a, hipStream_t s)
+// The one launch in front of the page kernels (brotlig_schedule.h): stream headers -> page prefix -> job records in schedule order ->
+// pairing policy.  A small batch (up to 64 streams, up to 2 048 pages) takes one workgroup that runs the phases one after the other;
+// anything else one workgroup per item of every phase, up to `g.sched` of them walking the pages (kSchedThreads pages per step each).
+constexpr uint64_t kSchedSmallPages = 2048;
+void launch_schedule(DecodeArgs& a, const Grids& g, hipStream_t s)
 {
-    const uint32_t groups = (a.num_streams + 63u) / 64u;
-    hipLaunchKernelGGL(brotlig_prepare_kernel, dim3(groups), dim3(64), 0, s, a);
-    if (groups > 1u) hipLaunchKernelGGL(brotlig_prepare_finish_kernel, dim3(groups), dim3(64), 0, s, a);
+    a.launch_tag = next_launch_tag();
+    const uint64_t pages = max_pages(a.num_streams, a.out_bytes);
+    unsigned grid = 1u;
+    if (a.num_streams > 64u || pages > kSchedSmallPages) {
+        // workgroups that walk the pages, kSchedThreads of them per step: as many as the batch has such groups of pages if its pages are the
+        // usual 64 KiB (with 32 KiB pages every workgroup takes two steps) -- the device starts a workgroup of this kernel every ~50 ns, and
+        // those that come late and find nothing to do are waited for all the same
+        const uint64_t groups = (a.out_bytes / 65536u + a.num_streams + kSchedThreads - 1u) / kSchedThreads;
+        grid = sched_grid(a.num_streams, (uint32_t)(groups < (uint64_t)g.sched ? groups : (uint64_t)g.sched));
+    }
+    hipLaunchKernelGGL(brotlig_schedule_kernel, dim3(grid), dim3(kSchedThreads), 0, s, a);
 }
 
 // prepare (page counts -> prefix) then the persistent page-decode kernel; k0/k1 bracket the latter
@@ -188,16 +209,10 @@ BROTLIG_ERROR enqueue(const DecodeArgs& args, hipStream_t s, hipEvent_t k0, hipE
     if (BROTLIG_ERROR e = grid_sizes(&g)) return e;
     DecodeArgs a = args;
     a.decode_waves = (uint16_t)std::min(classic_grid(a, g), 65535u);    // (schedule_mode: a batch of up to twice as many pages takes them folded)
-    HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), s));
-    launch_prepare(a, s);
-    if (a.order) {                                                      // page schedule: count, then scatter
-        hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g.order), dim3(64), 0, s, a);
-        hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, s, a);
-    }
     // the pairing policy only matters when two pages can meet in a wavefront: a batch that cannot hold more pages than the grid has
-    // wavefronts (every page >= 32 KiB of the output region) decodes one page per wavefront, and its launch is one kernel shorter
-    const bool may_pair = max_pages(a.num_streams, a.out_bytes) > (uint64_t)g.decode || g_debug_grid.load() != 0u;
-    if (may_pair) hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, s, a);
+    // wavefronts (every page >= 32 KiB of the output region) decodes one page per wavefront
+    a.may_pair = (max_pages(a.num_streams, a.out_bytes) > (uint64_t)g.decode || g_debug_grid.load() != 0u) ? 1u : 0u;
+    launch_schedule(a, g, s);
     if (diag_policy() >= 0)                             // diagnostics: pin the pairing policy (quarters of a page a free half waits)
         HIP_OK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.status + 3), diag_policy(), 1, s));
     if (k0) HIP_OK(hipEventRecord(k0, s));
@@ -261,8 +276,7 @@ extern "C" uint32_t DecompressedSize(uint8_t* src)
 extern "C" size_t BrotligDecodeWorkspaceSize(uint32_t num_streams) { return workspace_bytes(num_streams); }
 extern "C" size_t BrotligDecodeWorkspaceSizeFor(uint32_t num_streams, uint64_t out_bytes)
 {
-    size_t b = workspace_bytes(num_streams) + (size_t)(4u * max_pages(num_streams, out_bytes));
-    return b;
+    return jobs_offset(num_streams) + sizeof(JobRecord) * (size_t)max_pages(num_streams, out_bytes);
 }
 
 extern "C" BROTLIG_ERROR BrotligDecodeBatchDevice(const void* d_in, uint64_t in_bytes, void* d_out, uint64_t out_bytes,
@@ -644,19 +658,15 @@ extern "C" BROTLIG_ERROR BrotligDecodePhaseProfile(const void* d_in, uint64_t in
     Grids g;
     if (BROTLIG_ERROR e = grid_sizes(&g)) return e;
     DevBuf prof;
-    const size_t prof_words = (size_t)kNumPhases + 2u * (size_t)g.decode;   // phase sums, then {first, last} 100 MHz tick of every wavefront
+    // phase sums, then {first, last} 100 MHz tick of every wavefront, then {came, ticket, phase open, done} of the schedule kernel's tickets
+    const size_t prof_words = (size_t)kNumPhases + 2u * (size_t)g.decode + 4u * (size_t)kSchedTimedTickets;
     HIP_OK(hipMalloc(&prof.p, prof_words * sizeof(unsigned long long)));
     HIP_OK(hipMemset(prof.p, 0, prof_words * sizeof(unsigned long long)));
     DecodeArgs a = make_args(d_in, in_bytes, d_out, out_bytes, d_streams, num_streams, d_workspace, ws_bytes, d_scratch);
     a.prof = static_cast<unsigned long long*>(prof.p);
     a.decode_waves = (uint16_t)std::min(g.decode, 65535);
-    HIP_OK(hipMemsetAsync(a.status, 0, kWsHeaderWords * sizeof(uint32_t), nullptr));
-    launch_prepare(a, nullptr);
-    if (a.order) {
-        hipLaunchKernelGGL(brotlig_order_count_kernel, dim3(g.order), dim3(64), 0, nullptr, a);
-        hipLaunchKernelGGL(brotlig_order_scatter_kernel, dim3(g.order), dim3(64), 0, nullptr, a);
-    }
-    hipLaunchKernelGGL(brotlig_policy_kernel, dim3(1), dim3(64), 0, nullptr, a);
+    a.may_pair = 1u;
+    launch_schedule(a, g, nullptr);
     if (BROTLIG_WAVE_TIMES) hipLaunchKernelGGL(brotlig_decode_kernel, dim3(g.decode), dim3(64), 0, nullptr, a);     // (diagnostics build: the product kernel with wave times)
     else hipLaunchKernelGGL(brotlig_decode_kernel_timed, dim3(g.decode), dim3(64), 0, nullptr, a);
     HIP_OK(hipDeviceSynchronize());

@@ -37,32 +37,61 @@ struct DcTable {
     uint32_t item_prefix[kMaxMips + 1];     // de-conditioning work items before each mip: 64 per tile of 2 rows x 32 row chunks, every tile row
                                             // padded to whole super-tiles of 4 tiles (brotlig_decondition_kernel): a multiple of 256
     uint32_t format;                        // 1..5 = BC1..BC5, 0 = unknown (one byte per block)
+    uint32_t pad0;
+    // ---- the record's last 128 bytes: the words that cross workgroups INSIDE the schedule kernel (brotlig_schedule.h), written and read there
+    // with write-through stores / loads that look beyond the own L2.  A cache line of their own: everything above is written with ordinary
+    // stores by one workgroup and read by later kernels only.
     uint32_t status;                        // kStatus* bits of THIS stream (every stream has a record, pre-conditioned or not): which asset of a
                                             // batch was damaged (BrotligDecodeBatchStreamStatus); the batch-wide OR stays in DecodeArgs::status[0]
-    uint32_t chunk_pages;                   // in the record of every 64th stream: the pages of the 64 streams from it on (brotlig_prepare_kernel,
-                                            // one workgroup per 64 streams, to brotlig_prepare_finish_kernel)
     uint32_t super_base;                    // de-conditioning super-tiles of all streams before this one (every stream has the word; a stream that is
                                             // not pre-conditioned has none of its own): the batch's super-tiles are one list, cut evenly over the
                                             // wavefronts of brotlig_decondition_kernel
+    uint32_t chunk_pages;                   // in the record of every 64th stream: the pages of the 64 streams from it on (schedule kernel, phase
+                                            // "prepare": one item per 64 streams; summed by phase "scan")
     uint32_t chunk_supers;                  // like chunk_pages
-    uint32_t pad[29];
+    uint32_t chunk_precon;                  // like chunk_pages: pre-conditioned streams among the 64
+    uint32_t chunk_pages_before, chunk_supers_before;   // in the same records: what lies before the 64 streams (phase "scan" to phase "finalize")
+    uint32_t pad[25];
 };
+static_assert(__builtin_offsetof(DcTable, status) == 896, "the shared words begin the record's last 128-byte line");
 static_assert(sizeof(DcTable) == 1024, "DcTable is addressed as 1 KiB records");
+
+// One scheduled page as the page kernels take it: DecodeArgs::jobs[k] answers the k-th request of the page counter.  Written by the schedule
+// kernel (brotlig_schedule.h) from the page tables -- stream lookup, table walk (src/BrotligDecoder.cpp:310-314), bounds against the caller's
+// buffers, all done once per page THERE -- so that a page start is one 32-byte read instead of a chain of eight dependent loads (round 6;
+// rounds 1-5 kept one page INDEX per request and every page start walked from it: schedule word -> log2(streams) probes of the page prefix
+// -> descriptor -> stream header -> two page-table words).
+struct __attribute__((aligned(16))) JobRecord {
+    uint64_t in_off;        // byte offset of the compressed page in DecodeArgs::in
+    uint32_t in_size;       // its bytes (== out size: a stored page)
+    uint32_t shape;         // bytes it decodes to (bits 0..18) | page size index of its stream << 20 | stream pre-conditioned << 24 | valid << 25
+    uint64_t out_off;       // where they go: byte offset in DecodeArgs::out (DecodeArgs::scratch for a pre-conditioned stream)
+    uint32_t stream;        // index of its stream in the batch
+    uint32_t page;          // index of the page in its stream
+};
+static_assert(sizeof(JobRecord) == 32, "two 16-byte loads");
+enum : uint32_t { kJobPrecon = 1u << 24, kJobValid = 1u << 25 };
+
+// The schedule kernel's own words in the workspace header (DecodeArgs::sync): see brotlig_schedule.h.
+enum : uint32_t { kSyncCookie = 0u /* 64 bits: "the words below are clean" */, kSyncTicket = 2u /* tickets taken by the launch in progress */,
+                  kSyncDone = 4u /* [kSchedPhases] items finished per phase */, kSyncStatus = 12u /* kStatus* bits found by the schedule kernel */,
+                  kSyncWords = 16u };
 
 struct DecodeArgs {
     const uint8_t* in;  uint64_t in_bytes;
     uint8_t* out;       uint64_t out_bytes;
     uint8_t* scratch;   // conditioned-space staging for preconditioned streams (same layout as out)
     const StreamDesc* streams; uint32_t num_streams;
-    uint16_t decode_waves;  // the order kernels' business (schedule_mode below; in what was padding: the page kernels' code does not move): the wavefronts
-    uint16_t order_from_k;  // of brotlig_decode_kernel for this batch (0: unknown), and from how many pages on (in units of 1 024) a batch gets the schedule proper
-    uint32_t* page_base;    // [num_streams + 1] exclusive prefix of page counts
-    uint32_t* work_counter; // [1] next global page index
+    uint16_t decode_waves;  // the schedule kernel's business (schedule_mode): the wavefronts of brotlig_decode_kernel for this batch (0: unknown),
+    uint16_t order_from_k;  // and from how many pages on (in units of 1 024) a batch gets the schedule proper
+    uint32_t* page_base;    // [num_streams + 1] exclusive prefix of page counts; [num_streams] = pages of the batch, published LAST by the schedule kernel
+    uint32_t* work_counter; // [1] next request of the page kernels
     uint32_t* status;       // [0] OR of kStatus*, [2] number of preconditioned streams, [3] pairing policy, [5] de-conditioning super-tiles of the
-                            // batch (the end of the DcTable::super_base prefix), [8..8+B) pages per scheduling bucket, [8+B..8+2B) bucket fill
-                            // cursors (B = kBuckets <= 64; kStatusWords in all)
-    uint32_t* order;        // [order_cap] page schedule: global page indices grouped by bucket (null: page order)
-    uint32_t  order_cap;
+                            // batch (the end of the DcTable::super_base prefix), [6] pages of the batch (the schedule kernel's own copy), [8..8+B) pages
+                            // per scheduling bucket, [8+B..8+2B) bucket fill cursors (B = kBuckets <= 64; kStatusWords in all)
+    uint32_t* sync;         // [kSyncWords] tickets and phase counters of the schedule kernel
+    JobRecord* jobs;        // [jobs_cap] the page schedule: one record per request of the page counter (null: no room in the workspace -- the page
+    uint32_t  jobs_cap;     // kernels then take pages in stream order and walk the page tables themselves)
     uint32_t  duo_limit;    // batches of up to this many pages belong to brotlig_decode_duo_kernel (two wavefronts per page), larger ones to
                             // brotlig_decode_kernel: the host launches both when it cannot tell (it knows the output size, not the page
                             // count) and the one the batch does not belong to leaves at once.  0: never the former, ~0: always
@@ -70,15 +99,9 @@ struct DecodeArgs {
     uint16_t* far_syms;     // [workgroups of the decode grid][2][kFarSymStride] per 32-lane half: the ICP and distance symbols
                             // (canonical-code order) that do not fit the LDS arrays -- ranks kIcpSymCap.. and kDistSymCap..
     unsigned long long* prof;   // [kNumPhases] cycle sums, only written by the phase-timer instantiation
-#ifdef BROTLIG_WITH_SPLIT
-    // split path (profiles/experiments/split_path/brotlig_split_kernels.h): the entropy kernel leaves every compressed page as a command array and a
-    // literal array in global memory, the assembly kernel builds the page from them.  Slots are indexed by global page index.
-    uint64_t* cmds;             // [pages][cmd_cap + 1] packed commands, then one terminal entry
-    uint8_t*  lits;             // [pages][lit_stride] literals in consumption order
-    uint32_t* slot_hdr;         // [pages][2]: number of commands, flags (kSlot*)
-    uint32_t  cmd_cap, lit_stride;
-    uint32_t* work_counter2;    // [1] page counter of the assembly kernel
-#endif
+    uint64_t launch_tag;    // different for every launch of a process (never 0): marks a workspace that THIS launch is initialising, so that the
+                            // schedule kernel needs no memset in front of it (brotlig_schedule.h)
+    uint32_t may_pair;      // the batch may hold more pages than the page kernel has wavefronts: the pairing policy matters
 };
 
 // Phase timers (diagnostics build of the kernel only).

@@ -36,7 +36,7 @@ __device__ __forceinline__ bool start_pages(const DecodeArgs& a, Lds& L, PageJob
                                             uint32_t sl, uint16_t* far_syms, bool& tables_ok, OnPull on_pull, Clock& clk)
 {
     const uint32_t total = a.page_base[a.num_streams];
-    const uint32_t* const order = (a.order != nullptr && total <= a.order_cap) ? a.order : nullptr;
+    const JobRecord* const jobs = (a.jobs != nullptr && total <= a.jobs_cap) ? a.jobs : nullptr;
     uint32_t* const work_counter = a.work_counter;
     bool need = want, start = false;
     while (wave::any(need)) {
@@ -46,7 +46,7 @@ __device__ __forceinline__ bool start_pages(const DecodeArgs& a, Lds& L, PageJob
         const bool got = need && g < total;
         if (need && !got) { finished = true; need = false; }
         {
-            const PageJob nj = fetch_job(a, order, g, got);
+            const PageJob nj = fetch_job(a, jobs, g, got);
             if (got) job = nj;
         }
         if (got) on_pull(job);
@@ -281,7 +281,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
 
     const uint32_t resync_quarters = a.status[3];                       // pairing policy, set by the prepare kernel
     // ---- per-half state of the page under construction
-    PageJob job = fetch_job(a, nullptr, 0u, false);
+    PageJob job = no_job(a);
     bool live = false;               // inside a compressed page
     // kSolo (chosen per wavefront by decode_kernel_body): this wavefront decodes one page at a time, its upper half takes no pages
     // and helps with long copies instead.  A template parameter, not a flag: the two-page instantiation is compiled without it.

@@ -102,8 +102,35 @@ __device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// Hand-over between WORKGROUPS of one kernel through global memory (the schedule kernel's tickets, phase counters and the few words its
+// phases pass on, brotlig_schedule.h).  The device's XCDs have an L2 each, and ordinary loads and stores are cached there without
+// coherence: words that cross workgroups are therefore written and read with AGENT-scope relaxed atomics -- write-through stores, loads
+// that look beyond the own L2 -- and ordered by waiting for the own stores (stores_done) before the counter that announces them goes up.
+// Round 6's first version used agent-scope release / acquire FENCES instead: each is a write-back or an invalidation of the whole L2
+// (buffer_wbl2 / buffer_inv sc1), and two thousand workgroups doing that took 150 us for the work of 20.
+__device__ __forceinline__ uint32_t agent_load_relaxed(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t agent_load_relaxed64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_store_relaxed(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_store_relaxed64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t agent_add_relaxed(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// compare-and-swap: true when *p was `expect` and is `want` now; otherwise `expect` holds what *p was
+__device__ __forceinline__ bool agent_cas64(uint64_t* p, uint64_t& expect, uint64_t want)
+{
+    return __hip_atomic_compare_exchange_strong(p, &expect, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// every memory access this wavefront has issued so far is complete (its write-through stores have arrived) before anything it does afterwards;
+// also keeps the compiler from moving memory accesses across it
+// the same for code that only one lane runs (no wave-level barrier in it)
+__device__ __forceinline__ void lane_stores_done() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+__device__ __forceinline__ void stores_done()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 // Give the SIMD to the other wavefronts for a moment (inside a polling loop).
 __device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ void long_nap() { __builtin_amdgcn_s_sleep(8); }      // ~500 clocks: between looks at a word in global memory
 
 // Issue priority of this wavefront among the wavefronts of its SIMD (0 = default, anything else = raised): raised around a
 // round's longest dependent chain, so that the wave that is deepest in latency is served first.

@@ -17,21 +17,24 @@
 extern "C" {
 #endif
 
-/* ABI version of the device-pointer batch interface.  Version 3 (round 3): 32-byte BrotligStreamDesc (was 16), d_in must
- * extend 16 bytes past in_bytes, the workspace holds the per-wavefront symbol slots (+30 MiB: 8192 workgroups).  The entry points whose
- * contract changed carry the version in their SYMBOL names (the macros below), so a caller built against an older header
- * fails to link instead of passing descriptors of the wrong stride; BrotligAbiVersion() answers at run time (dlopen users).
- * Round 4 only ADDED entry points (BrotligDecodeBatchMultiDeviceAsync / ...Wait): the version stays 3.
- * Round 5 likewise (BrotligDecodeBatchStreamStatus, BrotligStreamerStreamResult, BrotligDebugKnobsEnabled); the per-stream status word
- * lives in what was padding of the workspace's per-stream record, so the workspace size and layout are those of version 3. */
-#define BROTLIG_AMD_ABI_VERSION 3
-#define BrotligDecodeWorkspaceSize      BrotligDecodeWorkspaceSize_v3
-#define BrotligDecodeWorkspaceSizeFor   BrotligDecodeWorkspaceSizeFor_v3
-#define BrotligDecodeBatchDevice        BrotligDecodeBatchDevice_v3
-#define BrotligDecodeBatchStatus        BrotligDecodeBatchStatus_v3
-#define BrotligDecodeBatchTimed         BrotligDecodeBatchTimed_v3
-#define BrotligDecodePhaseProfile       BrotligDecodePhaseProfile_v3
-#define BrotligDecodeBatchMultiDevice   BrotligDecodeBatchMultiDevice_v3
+/* ABI version of the device-pointer batch interface.  The entry points whose contract changes carry the version in their SYMBOL names
+ * (the macros below), so a caller built against an older header fails to link instead of passing buffers of the wrong layout;
+ * BrotligAbiVersion() answers at run time (dlopen users).
+ *   3 (round 3): 32-byte BrotligStreamDesc (was 16), d_in must extend 16 bytes past in_bytes, the workspace holds the per-wavefront symbol
+ *     slots (+30 MiB: 8192 workgroups).  Rounds 4 and 5 only ADDED entry points; round 5 also grew the workspace header by 1 KiB without
+ *     saying so -- a reason more for:
+ *   4 (round 6): the workspace's page schedule is one 32-byte job record per page (was one word), so BrotligDecodeWorkspaceSizeFor
+ *     returns more for the same batch, and the header holds the schedule kernel's counters.  Workspace sizes are never constants of a
+ *     caller: ask the LOADED library (BrotligDecodeWorkspaceSize / ...For).  A workspace smaller than ...SizeFor's answer still decodes --
+ *     in stream order, every page start walking the page tables -- as long as it has BrotligDecodeWorkspaceSize bytes; less is refused. */
+#define BROTLIG_AMD_ABI_VERSION 4
+#define BrotligDecodeWorkspaceSize      BrotligDecodeWorkspaceSize_v4
+#define BrotligDecodeWorkspaceSizeFor   BrotligDecodeWorkspaceSizeFor_v4
+#define BrotligDecodeBatchDevice        BrotligDecodeBatchDevice_v4
+#define BrotligDecodeBatchStatus        BrotligDecodeBatchStatus_v4
+#define BrotligDecodeBatchTimed         BrotligDecodeBatchTimed_v4
+#define BrotligDecodePhaseProfile       BrotligDecodePhaseProfile_v4
+#define BrotligDecodeBatchMultiDevice   BrotligDecodeBatchMultiDevice_v4
 uint32_t BrotligAbiVersion(void);
 
 /* inc/common/BrotligCommon.h:50-68 -- same enumerators, same numeric values */
@@ -105,10 +108,11 @@ typedef struct BrotligStreamDesc {
  * counts, pre-conditioning tables, and 30 MiB of per-wavefront slots (up to 8192 workgroups) for prefix-code symbols beyond
  * the kernel's LDS arrays (kept small so that 16 wavefronts fit a compute unit).  One workspace per batch in flight. */
 size_t BrotligDecodeWorkspaceSize(uint32_t num_streams);
-/* Workspace size that also holds the page schedule for `out_bytes` of output (one word per page): with
- * it, batches of 768 MiB and more are decoded bucket by bucket, similar pages side by side (about 12 %
- * faster on mixed data), and batches of between one and two pages per wavefront of the page kernel
- * (256 .. 512 MiB of 64 KiB pages on an MI355X) densest page next to lightest.  BrotligDecodeWorkspaceSize is the minimum; anything in between works. */
+/* Workspace size that also holds the page schedule for `out_bytes` of output (one 32-byte job record per page the batch can hold: 1 KiB
+ * per MiB of output): with it a page start is one read of its record instead of a walk through the page tables, batches of 768 MiB and
+ * more are decoded bucket by bucket, similar pages side by side (about 12 % faster on mixed data), and batches of between one and two
+ * pages per wavefront of the page kernel (256 .. 512 MiB of 64 KiB pages on an MI355X) densest page next to lightest.
+ * BrotligDecodeWorkspaceSize is the minimum; a workspace in between is used like the minimum. */
 size_t BrotligDecodeWorkspaceSizeFor(uint32_t num_streams, uint64_t out_bytes);
 
 /* Enqueue the decode of `num_streams` streams.

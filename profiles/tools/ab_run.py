@@ -28,10 +28,16 @@ def main():
     libs = sorted(glob.glob(os.path.join(a.dir, "lib_*.so")), key=lambda p: (os.path.basename(p) != "lib_base.so", p))
     names = [os.path.basename(p)[4:-3] for p in libs]
     results = {}
-    for w in a.workloads:
-        streams, expected = bench.build_streams(w, list(range(256 if w == "bc3" else 16)), 256 if w == "bc3" else 4096, 8 if w == "bc3" else a.distinct)
+    for spec in a.workloads:
+        # "mixed", or "runs:1" (streams), or "mixed:16:64" (streams, pages per stream): round 6, for what a step costs beside its page kernel
+        w, *shape = spec.split(":")
+        nstreams = int(shape[0]) if shape else (256 if w == "bc3" else 16)
+        npages = int(shape[1]) if len(shape) > 1 else (256 if w == "bc3" else 4096)
+        streams, expected = bench.build_streams(w, list(range(nstreams)), npages, 8 if w == "bc3" else min(a.distinct, npages))
+        w = spec
         out_sizes = [len(e) for e in expected] if w == "bc3" else None
         per = {n: [] for n in names}
+        step = {n: [] for n in names}
         rest = {}
         exact = {}
         for rep in range(a.reps):
@@ -48,8 +54,9 @@ def main():
                         ok = ok and bool((got == exp.unsqueeze(0)).all())
                     exact[n] = ok
                 total, kern = dec.timed(2, a.steps)
-                per[n].append(kern if w != "bc3" else total / a.steps)
-                if w == "bc3":      # what the step takes beside the page kernel: prepare + de-conditioning
+                per[n].append(kern if not w.startswith("bc3") else total / a.steps)
+                step[n].append(total / a.steps)
+                if w.startswith("bc3"):      # what the step takes beside the page kernel: prepare + de-conditioning
                     rest.setdefault(n, []).append(total / a.steps - kern)
                 U = dec.decompressed_bytes
                 del dec
@@ -58,11 +65,13 @@ def main():
         for n in names:
             best = min(per[n])
             results.setdefault(w, {})[n] = {"ms": [round(x, 4) for x in per[n]], "best_ms": round(best, 4), "GBps": round(U / best / 1e6, 1),
-                                            "vs_base_pct": round((base / best - 1) * 100, 2), "bit_exact": exact[n]}
+                                            "vs_base_pct": round((base / best - 1) * 100, 2), "bit_exact": exact[n],
+                                            "step_ms": round(min(step[n]), 4), "step_minus_kernel_us": round((min(step[n]) - best) * 1e3, 1) if not w.startswith("bc3") else None,
+                                            "step_GBps": round(U / min(step[n]) / 1e6, 1)}
             if n in rest:
                 results[w][n]["step_minus_page_kernel_ms"] = round(min(rest[n]), 4)
                 print(f"{w:10s} {n:28s} step - page kernel (prepare + de-conditioning): {min(rest[n]):.4f} ms", flush=True)
-            print(f"{w:10s} {n:28s} best {best:8.4f} ms  {U / best / 1e6:7.1f} GB/s  {100 * (base / best - 1):+6.2f} %  exact {exact[n]}  runs {[round(x, 3) for x in per[n]]}", flush=True)
+            print(f"{w:14s} {n:24s} best {best:8.4f} ms  {U / best / 1e6:7.1f} GB/s  {100 * (base / best - 1):+6.2f} %  step {min(step[n]):8.4f} ms ({U / min(step[n]) / 1e6:7.1f} GB/s)  exact {exact[n]}  runs {[round(x, 3) for x in per[n]]}", flush=True)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(results, open(a.out, "w"), indent=1)

@@ -45,6 +45,17 @@ inline void set_priority(int) {}
 inline uint32_t lds_load_acquire(const uint32_t* p) { return *(const volatile uint32_t*)p; }
 inline void lds_store_release(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
 inline void nap() { sim::yield_to_scheduler(); }      // let the other wave of the workgroup run
+// between workgroups (the schedule kernel): the simulator runs one workgroup at a time, in blockIdx order -- whatever a workgroup waits for
+// was finished by an earlier one, or the kernel's ordering argument is broken (the polling loops of brotlig_schedule.h give up and say so)
+inline uint32_t agent_load_relaxed(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+inline uint64_t agent_load_relaxed64(const uint64_t* p) { return *(const volatile uint64_t*)p; }
+inline void agent_store_relaxed(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+inline void agent_store_relaxed64(uint64_t* p, uint64_t v) { *(volatile uint64_t*)p = v; }
+inline uint32_t agent_add_relaxed(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+inline bool agent_cas64(uint64_t* p, uint64_t& expect, uint64_t want) { if (*p == expect) { *p = want; return true; } expect = *p; return false; }
+inline void long_nap() {}
+inline void lane_stores_done() {}
+inline void stores_done(int site = __builtin_LINE()) { sim::collective_enter(0, 0, site); }
 inline uint32_t other_half(uint32_t v, SIM_SITE)
 {
     const int s = sim::collective_enter(v, 0, site);

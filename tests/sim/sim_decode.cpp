@@ -6,27 +6,34 @@
 #include <brotlig_wave_ops.h>
 
 #include "brotlig_kernels.h"
-#ifdef BROTLIG_WITH_SPLIT       // the two-kernel experiment of round 3 (profiles/experiments/split_path/): only tests/test_sim_split.py builds it in
-#include "brotlig_split_kernels.h"
-#endif
 
 using namespace brotlig;
 
 static uint32_t g_last_policy = 0;
 static int g_use_order = 1;      // page schedule on (the GPU host code only uses it for large batches)
 static uint16_t g_order_from_k = 0;   // DecodeArgs::order_from_k: 0 = every batch gets the schedule proper (the host: from 12 x 1 024 pages on)
-static void prepare_body(void* p) { brotlig_prepare_kernel(*(DecodeArgs*)p); }
-static void prepare_finish_body(void* p) { brotlig_prepare_finish_kernel(*(DecodeArgs*)p); }
-// the host's launch_prepare (csrc/brotlig_hip.hip): one workgroup per 64 streams, the second kernel for more than 64 streams
-static void run_prepare(DecodeArgs& a)
+// the host's launch_schedule (csrc/brotlig_hip.hip): one workgroup for a small batch, else one per item of every phase.  g_sched_workers
+// pins the count / scatter workers (0: the host's rule with a small device); g_sched_force_tickets sends small batches through tickets too
+static int g_fresh_workspace = 0;
+extern "C" void sim_set_fresh_workspace(int on) { g_fresh_workspace = on; }
+static uint32_t g_sched_workers = 0, g_sched_force_tickets = 0, g_last_sched_grid = 0;
+static uint64_t g_launch_tag = 0x5EED000000ull;
+extern "C" void sim_set_schedule(uint32_t workers, uint32_t force_tickets) { g_sched_workers = workers; g_sched_force_tickets = force_tickets; }
+extern "C" uint32_t sim_last_schedule_grid() { return g_last_sched_grid; }
+static void schedule_body(void* p) { brotlig_schedule_kernel(*(DecodeArgs*)p); }
+static void run_schedule(DecodeArgs& a)
 {
-    const uint32_t groups = (a.num_streams + 63u) / 64u;
-    sim::run_grid(groups, prepare_body, &a);
-    if (groups > 1u) sim::run_grid(groups, prepare_finish_body, &a);
+    a.launch_tag = ++g_launch_tag & ((1ull << 40) - 1u);
+    const uint64_t pages = a.out_bytes / kMinPageSize + a.num_streams;
+    uint32_t grid = 1u;
+    if (a.num_streams > 64u || pages > 2048u || g_sched_force_tickets) {
+        const uint64_t groups = (pages + kSchedThreads - 1u) / kSchedThreads;
+        // (a pinned worker count is taken as it is: more workgroups than groups of pages -- the surplus finds no page and only counts itself done)
+        grid = sched_grid(a.num_streams, g_sched_workers ? g_sched_workers : (uint32_t)(groups < 3u ? groups : 3u));
+    }
+    g_last_sched_grid = grid;
+    sim::run_grid(grid, schedule_body, &a, (int)(kSchedThreads / 64u));
 }
-static void order_count_body(void* p) { brotlig_order_count_kernel(*(DecodeArgs*)p); }
-static void order_scatter_body(void* p) { brotlig_order_scatter_kernel(*(DecodeArgs*)p); }
-static void policy_body(void* p) { brotlig_policy_kernel(*(DecodeArgs*)p); }
 static void decode_body(void* p) { brotlig_decode_kernel(*(DecodeArgs*)p); }
 static void duo_body(void* p) { brotlig_decode_duo_kernel(*(DecodeArgs*)p); }
 static int g_duo = 0;          // small-batch form: two wavefronts per page (brotlig_decode_duo_kernel)
@@ -59,27 +66,32 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
         sd[i].in_size = (i + 1 < num_streams ? in_offsets[i + 1] : in_bytes) - in_offsets[i];        // streams lie back to back
         sd[i].out_capacity = (i + 1 < num_streams ? out_offsets[i + 1] : out_bytes) - out_offsets[i];
     }
-    std::vector<uint32_t> page_base(num_streams + 1, 0);
-    uint32_t counter = 0;
-    uint32_t status_words[kStatusWords] = {0};
+    // the workspace header as the device has it (the schedule kernel needs no memset in front of it): garbage in a fresh workspace -- the first
+    // batch of a process here, and every batch after sim_set_fresh_workspace(1) --, what the last batch left otherwise
+    static uint32_t stale = 0x1234567u;
+    std::vector<uint32_t> page_base(num_streams + 1, stale);
+    uint32_t counter = stale;
+    alignas(8) static uint32_t status_words[kStatusWords + kSyncWords];
+    static bool have_header = false;
+    if (!have_header || g_fresh_workspace) for (uint32_t& w : status_words) w = (stale = stale * 1664525u + 1013904223u);
+    have_header = true;
     std::vector<DcTable> dc(num_streams);
     DecodeArgs a{};
     a.in = in; a.in_bytes = in_bytes; a.out = out; a.out_bytes = out_bytes; a.scratch = scratch;
     a.streams = sd.data(); a.num_streams = num_streams;
-    a.page_base = page_base.data(); a.work_counter = &counter; a.status = status_words; a.dc = dc.data();
-    std::vector<uint32_t> order(g_use_order ? (size_t)(out_bytes / 32768 + num_streams + 1) : 0);
-    if (g_use_order) { a.order = order.data(); a.order_cap = (uint32_t)order.size(); }
+    a.page_base = page_base.data(); a.work_counter = &counter; a.status = status_words; a.sync = status_words + kStatusWords; a.dc = dc.data();
+    std::vector<JobRecord> jobs(g_use_order ? (size_t)(out_bytes / 32768 + num_streams + 1) : 0);
+    if (g_use_order) { a.jobs = jobs.data(); a.jobs_cap = (uint32_t)jobs.size(); }
     const int decode_grid = grid ? grid : 4;
     a.order_from_k = g_order_from_k;
     a.decode_waves = (uint16_t)decode_grid;     // (the schedule proper for every batch, order_from_k = 0 -- except the batches schedule_mode folds)
     std::vector<uint16_t> far_syms((size_t)decode_grid * 2u * kFarSymStride, 0xFFFFu);     // stale garbage between pages, as on the device
     a.far_syms = far_syms.data();
-    run_prepare(a);
-    if (a.order) { sim::run_grid(3, order_count_body, &a); sim::run_grid(3, order_scatter_body, &a); }
+    const uint64_t bound = out_bytes / kMinPageSize + num_streams;
+    a.may_pair = (!g_host_rule_limit || bound > (uint64_t)decode_grid) ? 1u : 0u;       // as enqueue(): the policy only when two pages can meet in a wavefront
+    run_schedule(a);
     if (g_host_rule_limit) {
-        // as enqueue(): the policy kernel only when two pages can meet in a wavefront; both decode kernels, the device decides
-        const uint64_t bound = out_bytes / kMinPageSize + num_streams;
-        if (bound > (uint64_t)decode_grid) sim::run_grid(1, policy_body, &a);
+        // as enqueue(): both decode kernels, the device decides
         a.duo_limit = g_host_rule_limit;
         ++g_duo_launches;
         sim::run_grid(decode_grid, duo_body, &a, 2);
@@ -87,7 +99,6 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
         sim::run_grid(decode_grid, decode_body, &a);
         g_pages_by_classic = counter - g_pages_by_duo;
     } else {
-        sim::run_grid(1, policy_body, &a);
         if (g_duo) { ++g_duo_launches; a.duo_limit = 0xFFFFFFFFu; sim::run_grid(decode_grid, duo_body, &a, 2); a.duo_limit = 0u; }
         else sim::run_grid(decode_grid, decode_body, &a);
     }
@@ -100,49 +111,6 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
     return 0;
 }
 
-#ifdef BROTLIG_WITH_SPLIT
-static void entropy_body(void* p) { brotlig_entropy_kernel(*(DecodeArgs*)p); }
-static void assemble_body(void* p) { brotlig_assemble_kernel(*(DecodeArgs*)p); }
-static void assemble_global_body(void* p) { brotlig_assemble_global_kernel(*(DecodeArgs*)p); }
-static void assemble_page_body(void* p) { brotlig_assemble_page_kernel(*(DecodeArgs*)p); }
-static int g_run_assemble = 0;
-static uint8_t* g_scratch = nullptr;
-extern "C" void sim_set_scratch(uint8_t* p) { g_scratch = p; }
-extern "C" void sim_set_assemble(int on) { g_run_assemble = on; }
-
-// Split path, first kernel only: the command / literal arrays of every page, for inspection by the tests.
-// cmds: [pages][cmd_cap + 1], lits: [pages][lit_stride], hdr: [pages][2]
-extern "C" int sim_entropy_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* out, uint64_t out_bytes,
-                                 const uint64_t* in_offsets, const uint64_t* out_offsets, uint32_t num_streams, uint32_t grid,
-                                 uint64_t* cmds, uint8_t* lits, uint32_t* hdr, uint32_t cmd_cap, uint32_t lit_stride, uint32_t* status_out)
-{
-    std::vector<StreamDesc> sd(num_streams);
-    for (uint32_t i = 0; i < num_streams; ++i) {
-        sd[i].in_offset = in_offsets[i]; sd[i].out_offset = out_offsets[i];
-        sd[i].in_size = (i + 1 < num_streams ? in_offsets[i + 1] : in_bytes) - in_offsets[i];
-        sd[i].out_capacity = (i + 1 < num_streams ? out_offsets[i + 1] : out_bytes) - out_offsets[i];
-    }
-    std::vector<uint32_t> page_base(num_streams + 1, 0);
-    uint32_t counter = 0, counter2 = 0;
-    uint32_t status_words[kStatusWords] = {0};
-    std::vector<DcTable> dc(num_streams);
-    DecodeArgs a{};
-    a.in = in; a.in_bytes = in_bytes; a.out = out; a.out_bytes = out_bytes; a.scratch = g_scratch;
-    a.streams = sd.data(); a.num_streams = num_streams;
-    a.page_base = page_base.data(); a.work_counter = &counter; a.work_counter2 = &counter2; a.status = status_words; a.dc = dc.data();
-    const int decode_grid = grid ? grid : 4;
-    std::vector<uint16_t> far_syms((size_t)decode_grid * 2u * kFarSymStride, 0xFFFFu);
-    a.far_syms = far_syms.data();
-    a.cmds = cmds; a.lits = lits; a.slot_hdr = hdr; a.cmd_cap = cmd_cap; a.lit_stride = lit_stride;
-    run_prepare(a);
-    sim::run_grid(1, policy_body, &a);
-    sim::run_grid(decode_grid, entropy_body, &a);
-    if (g_run_assemble == 3) { sim::run_grid(decode_grid, assemble_page_body, &a, (int)kPageWaves); sim::run_grid(3, decond_body, &a); }
-    else if (g_run_assemble) { sim::run_grid(decode_grid, g_run_assemble == 2 ? assemble_global_body : assemble_body, &a); sim::run_grid(3, decond_body, &a); }
-    *status_out = status_words[0];
-    return 0;
-}
-#endif  // BROTLIG_WITH_SPLIT
 
 extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word 3: pairing policy chosen by the prepare kernel
 extern "C" void sim_set_order(int on) { g_use_order = on; }

@@ -102,6 +102,7 @@ static const SimBlockIdx blockIdx;
 static const SimGridDim gridDim;
 
 inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 inline int __ffs(int x) { return __builtin_ffs(x); }
 inline uint32_t __brev(uint32_t x)

@@ -21,9 +21,9 @@ def declared_functions():
 def test_library_exports_every_declared_symbol():
     so = ctypes.CDLL(_build.build_hip())
     names = declared_functions()
-    assert {"DecompressedSize", "DecodeGPU", "BrotligDecodeBatchDevice_v3", "BrotligDecodeBatchStatus_v3",
-            "BrotligDecodeBatchTimed_v3", "BrotligDecodeWorkspaceSize_v3", "BrotligDeviceSelfTest", "BrotligShardPlan",
-            "BrotligDecodeBatchMultiDevice_v3", "BrotligContextCreate", "BrotligAbiVersion"} <= set(names)
+    assert {"DecompressedSize", "DecodeGPU", "BrotligDecodeBatchDevice_v4", "BrotligDecodeBatchStatus_v4",
+            "BrotligDecodeBatchTimed_v4", "BrotligDecodeWorkspaceSize_v4", "BrotligDeviceSelfTest", "BrotligShardPlan",
+            "BrotligDecodeBatchMultiDevice_v4", "BrotligContextCreate", "BrotligAbiVersion"} <= set(names)
     for n in names:
         assert hasattr(so, n), n
 
@@ -77,7 +77,7 @@ def test_stale_callers_fail_to_link():
     caller built against an older header would ask for are not exported."""
     so = ctypes.CDLL(_build.build_hip())
     so.BrotligAbiVersion.restype = ctypes.c_uint32
-    assert so.BrotligAbiVersion() == 3
+    assert so.BrotligAbiVersion() == 4
     for n in ("BrotligDecodeBatchDevice", "BrotligDecodeBatchTimed", "BrotligDecodeWorkspaceSize", "BrotligDecodeBatchStatus"):
         assert not hasattr(so, n), n
 

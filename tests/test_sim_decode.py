@@ -19,10 +19,7 @@ SIM_DIR = os.path.join(ROOT, "tests", "sim")
 CSRC = os.path.join(ROOT, "brotli_g_sdk_amd", "csrc")
 
 
-SPLIT_DIR = os.path.join(ROOT, "profiles", "experiments", "split_path")
-
-
-def build_sim(name, flags=(), split=False):
+def build_sim(name, flags=()):
     # BROTLIG_SIM_FLAGS="-DBROTLIG_TUNE_X=1 ...": the whole simulator suite on a non-default build of the kernel source
     # (how the A/B variants of profiles/tools/ab_variants.sh are checked for bit-exactness before they go to the GPU box)
     extra = os.environ.get("BROTLIG_SIM_FLAGS", "").split()
@@ -34,12 +31,11 @@ def build_sim(name, flags=(), split=False):
     srcs = [os.path.join(SIM_DIR, f) for f in ("sim_decode.cpp", "sim_runtime.cpp")]
     deps = srcs + [os.path.join(SIM_DIR, f) for f in ("sim_runtime.h", "brotlig_wave_ops.h")] + \
         _build.kernel_headers()
-    if split:       # the two-kernel experiment of round 3 lives with the other experiments, outside the package (tests/test_sim_split.py)
-        deps.append(os.path.join(SPLIT_DIR, "brotlig_split_kernels.h"))
-        flags = list(flags) + ["-DBROTLIG_WITH_SPLIT", "-I", SPLIT_DIR]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         tmp = f"{so}.{os.getpid()}.tmp"             # built aside and moved into place: pytest-xdist workers may get here together
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-I", SIM_DIR, "-I", CSRC, "-o", tmp] + list(flags) + srcs)
+        # (BROTLIG_SCHED_SPIN_LIMIT: the simulator runs the workgroups of the schedule kernel one after the other in ticket order -- a wait that
+        # has to wait there is a broken ordering argument, and the kernel gives up after four looks instead of 2^25)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DBROTLIG_SCHED_SPIN_LIMIT=4", "-I", SIM_DIR, "-I", CSRC, "-o", tmp] + list(flags) + srcs)
         os.replace(tmp, so)
     L = ctypes.CDLL(so)
     L.sim_decode_batch.restype = ctypes.c_int
@@ -202,6 +198,70 @@ def test_sim_page_schedule_on_and_off(sim):
                 assert np.array_equal(o, d)
     finally:
         sim.sim_set_order(1)
+
+
+@pytest.mark.parametrize("workers,fresh", [(1, 1), (2, 0), (5, 1), (3, 0)])
+@pytest.mark.parametrize("schedule", ["proper", "page_order", "folded"])
+def test_sim_schedule_kernel_by_tickets(sim, workers, fresh, schedule):
+    """Round 6: the ONE kernel in front of the page decode (csrc/brotlig_schedule.h) with its workgroups as ticket holders -- prepare, count,
+    scatter, policy items waiting for the phase before them -- instead of the one workgroup a batch this small gets from the host: plain,
+    stored and pre-conditioned streams and a damaged one, with 1 .. 5 workgroups walking the pages, in a fresh workspace (garbage where the
+    kernel keeps its counters: one workgroup initialises them, the others wait for its cookie) and in one the last batch left clean, under
+    each of the three things the schedule can be.  Every record leads a page kernel to the right bytes; the damaged stream is named."""
+    from fuzzcases import simple_code_one_symbol
+    datas = [D.mixed(65536 * 9 + 4321, 11), D.runs(65536 * 3, 12), D.random_bytes(65536 * 2 + 17, 13), D.text(70000, 15)]
+    streams = [E.encode(d) for d in datas]
+    tex = D.bc_texture(3, 64, 48, seed=14)
+    streams.append(E.encode(tex, precondition=dict(format=3, width_blocks=64, height_blocks=48, swizzle=True, delta=True)))
+    datas.append(tex)
+    bad, cap = simple_code_one_symbol()
+    streams.append(bad)
+    sizes = [len(d) for d in datas] + [cap]
+    sim.sim_stream_status.restype = ctypes.c_uint32
+    sim.sim_stream_status.argtypes = [ctypes.c_uint32]
+    sim.sim_last_schedule_grid.restype = ctypes.c_uint32
+    sim.sim_set_order_from_k.argtypes = [ctypes.c_uint32]
+    # 21 pages: page order when the schedule proper starts at 1 024 pages; folded on 16 wavefronts (16 < 21 <= 32); the schedule proper on 4
+    grid = {"proper": 4, "page_order": 4, "folded": 16}[schedule]
+    sim.sim_set_order_from_k(1 if schedule == "page_order" else 0)
+    sim.sim_set_schedule(workers, 1)
+    sim.sim_set_fresh_workspace(fresh)
+    try:
+        for _ in range(2):                  # (the second batch finds what the first one left)
+            outs, status = run_batch(sim, streams, sizes, precon=True, grid=grid)
+            assert sim.sim_last_schedule_grid() == 1 + 2 * workers            # prepare, count and scatter items (the last of these runs the policy)
+            assert status == 2
+            assert [i for i in range(len(streams)) if sim.sim_stream_status(i)] == [len(streams) - 1]
+            for o, d in zip(outs, datas):
+                assert np.array_equal(o, d)
+    finally:
+        sim.sim_set_schedule(0, 0)
+        sim.sim_set_fresh_workspace(0)
+        sim.sim_set_order_from_k(0)
+
+
+def test_sim_schedule_kernel_many_streams_by_tickets(sim):
+    """More than 64 streams: the scan and finalize phases between prepare and count (chunks of 64 streams, their page totals summed by one
+    item, added back by the next).  200 small streams, some of them stored, one refused by its header; 1, then 4 workgroups walk the pages."""
+    rng = np.random.default_rng(7)
+    makers = [D.text, D.records, D.samples16, D.runs, D.mixed, D.random_bytes]
+    datas = [makers[i % 6](int(rng.integers(1, 140000)), 9000 + i) for i in range(200)]
+    streams = [E.encode(d) for d in datas]
+    hb = streams[77].copy(); hb[0] ^= 0x40; streams[77] = hb
+    sim.sim_stream_status.restype = ctypes.c_uint32
+    sim.sim_stream_status.argtypes = [ctypes.c_uint32]
+    sim.sim_last_schedule_grid.restype = ctypes.c_uint32
+    try:
+        for workers in (1, 4):
+            sim.sim_set_schedule(workers, 1)
+            outs, status = run_batch(sim, streams, [len(d) for d in datas], grid=6)
+            assert sim.sim_last_schedule_grid() == 4 + 1 + 1 + 2 * workers           # 4 chunks, scan, one finalize item, workers
+            assert status == 1 and [i for i in range(200) if sim.sim_stream_status(i)] == [77]
+            for i, (o, d) in enumerate(zip(outs, datas)):
+                if i != 77:
+                    assert np.array_equal(o, d), i
+    finally:
+        sim.sim_set_schedule(0, 0)
 
 
 @pytest.mark.parametrize("name,thunk,kw", raw_stress_cases()[1::2], ids=[c[0] for c in raw_stress_cases()[1::2]])
