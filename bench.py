@@ -50,6 +50,7 @@ def build_bc3_streams(indices, distinct):
     return streams, expected
 
 
+FILES_MANIFEST = []      # --workload files: (kind, path, offset, bytes) of every piece read (datagen.files)
 ENCODER_FLAGS = 0        # brotli_g_sdk_amd.encoder flags for the synthetic streams (--encoder-flags)
 PREENCODED = None      # optional {stream index: encoded `distinct`-page stream}, see --preencoded
 
@@ -79,6 +80,9 @@ def build_streams(kind, indices, pages_per_stream, distinct):
             data = D.records(distinct * PAGE, seed)
         elif kind == "samples16":
             data = D.samples16(distinct * PAGE, seed)
+        elif kind == "files":
+            # real bytes (round 6): files the image ships -- shared objects, Python sources, C++ headers, /usr/share -- instead of a generator
+            data = D.files(distinct * PAGE, seed, manifest=FILES_MANIFEST)
         else:
             raise SystemExit(f"unknown workload {kind}")
         small = PREENCODED[seed] if PREENCODED is not None and seed in PREENCODED else E.encode(data, flags=ENCODER_FLAGS)
@@ -220,7 +224,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="mixed", choices=["mixed", "mixed_sorted", "runs", "text", "records", "samples16", "bc3"])
+    ap.add_argument("--workload", default="mixed", choices=["mixed", "mixed_sorted", "runs", "text", "records", "samples16", "bc3", "files"])
     ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--pages-per-stream", type=int, default=4096)
     ap.add_argument("--distinct", type=int, default=256, help="distinct encoded pages per stream (tiled)")
@@ -403,7 +407,7 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "bit_exact": ok,
             "config": {"workload": (f"{args.streams} streams x {args.pages_per_stream} pages x 64 KiB per GPU "
-                                    f"({per_rank_u / 2**30:.2f} GiB), '{args.workload}' synthetic "
+                                    f"({per_rank_u / 2**30:.2f} GiB), '{args.workload}' {'real files' if args.workload == 'files' else 'synthetic'} "
                                     f"(BASELINE.json configs[2] when mixed), {distinct} distinct encoded pages per stream "
                                     f"tiled, compression ratio {per_rank_u / per_rank_c:.2f}" + (f", encoder flags {args.encoder_flags}" if args.encoder_flags or args.preencoded else "")) if args.workload != "bc3" else
                                    (f"{args.streams} BC3 textures of {BC3_BLOCKS}x{BC3_BLOCKS} blocks (16 MiB, 256 pages each, "
@@ -417,6 +421,10 @@ def main():
                          "algorithmic_bytes_per_launch": roof_bytes, "kernel_source_sha16": ksha, "kernel_disasm_sha16": dsha},
             "cpu_baseline": cpu,
         }
+        if args.workload == "files":
+            from brotli_g_sdk_amd import datagen as D
+            line["data"] = "real files of the image (datagen.files), tiled"
+            line["config"]["files"] = D.files_manifest_summary(FILES_MANIFEST[:len(FILES_MANIFEST) // (2 if alt is not None else 1)])
         if alt is not None:
             line["alt"] = alt
         if world > 1:

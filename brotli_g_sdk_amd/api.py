@@ -133,6 +133,24 @@ def lib():
         L.BrotligStreamerWait.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
         L.BrotligStreamerOutput.restype = ctypes.c_void_p
         L.BrotligStreamerOutput.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+        try:
+            L.BrotligStreamerCreateDeviceOutput.restype = ctypes.c_int
+            L.BrotligStreamerCreateDeviceOutput.argtypes = L.BrotligStreamerCreate.argtypes
+            L.BrotligStreamerDeviceOutput.restype = ctypes.c_int
+            L.BrotligStreamerDeviceOutput.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p),
+                                                      ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_void_p)]
+            L.BrotligStreamerConsumerDone.restype = ctypes.c_int
+            L.BrotligStreamerConsumerDone.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+            L.BrotligStreamerStreamWait.restype = ctypes.c_int
+            L.BrotligStreamerStreamWait.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+            L.BrotligStreamerAcquire.restype = ctypes.c_int
+            L.BrotligStreamerAcquire.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64)]
+            L.BrotligStreamerSubmitInPlace.restype = ctypes.c_int
+            L.BrotligStreamerSubmitInPlace.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                       ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        except AttributeError:
+            if not os.environ.get("BROTLIG_HIP_SO"):        # (an A/B build of an older source)
+                raise
         _lib = L
     return _lib
 
@@ -435,11 +453,15 @@ class Streamer:
         outs = st.result(t)                     # list of uint8 arrays (copies out of the pinned buffer)
     """
 
-    def __init__(self, slots=3, slot_in_bytes=64 << 20, slot_out_bytes=256 << 20, max_streams=4096):
+    def __init__(self, slots=3, slot_in_bytes=64 << 20, slot_out_bytes=256 << 20, max_streams=4096, device_output=False):
+        """device_output=True (round 6): the decoded bytes stay in device memory -- nothing is downloaded, no pinned staging for them;
+        `device_output(ticket, i)` says where stream i of a batch is and which event to wait for."""
         self._h = ctypes.c_void_p()
-        rc = lib().BrotligStreamerCreate(slots, slot_in_bytes, slot_out_bytes, max_streams, ctypes.byref(self._h))
+        self.device_output_mode = bool(device_output)
+        create = lib().BrotligStreamerCreateDeviceOutput if device_output else lib().BrotligStreamerCreate
+        rc = create(slots, slot_in_bytes, slot_out_bytes, max_streams, ctypes.byref(self._h))
         if rc != BROTLIG_OK:
-            raise BrotligError(rc, "BrotligStreamerCreate")
+            raise BrotligError(rc, "BrotligStreamerCreateDeviceOutput" if device_output else "BrotligStreamerCreate")
         self._keep = {}
 
     def close(self):
@@ -472,6 +494,31 @@ class Streamer:
         self._keep[t.value] = (n, outputs)          # the caller's output arrays must outlive the batch
         return t.value
 
+    def acquire(self):
+        """BrotligStreamerAcquire: the pinned staging area of the slot the next batch goes to, as a writable uint8 array (no copy) -- a loader
+        reads its streams straight into it, at 16-byte aligned ascending offsets, and calls submit_in_place."""
+        p, cap = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = lib().BrotligStreamerAcquire(self._h, ctypes.byref(p), ctypes.byref(cap))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligStreamerAcquire")
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(cap.value,))
+
+    def submit_in_place(self, offsets, sizes, outputs=None):
+        """BrotligStreamerSubmitInPlace: the streams lie in the acquired staging area at `offsets` (bytes `sizes`)."""
+        n = len(offsets)
+        offs = (ctypes.c_uint64 * n)(*[int(o) for o in offsets])
+        szs = (ctypes.c_uint32 * n)(*[int(x) for x in sizes])
+        outs = caps = None
+        if outputs is not None:
+            outs = (ctypes.c_void_p * n)(*[(o.ctypes.data if o is not None else None) for o in outputs])
+            caps = (ctypes.c_uint32 * n)(*[(o.size if o is not None else 0) for o in outputs])
+        t = ctypes.c_uint64()
+        rc = lib().BrotligStreamerSubmitInPlace(self._h, n, offs, szs, outs, caps, ctypes.byref(t))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligStreamerSubmitInPlace")
+        self._keep[t.value] = (n, outputs)
+        return t.value
+
     def wait(self, ticket):
         """Waits for the batch; its `outputs` arrays (if any were given) are filled on return.  Also valid for a
         batch that a later submit() had to complete to make room (one generation back)."""
@@ -493,6 +540,38 @@ class Streamer:
         if not p:
             return None
         return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(sz.value,)).copy()
+
+    def device_output(self, ticket, index):
+        """BrotligStreamerDeviceOutput: (device pointer, size, hipEvent_t) of one stream of a batch of a device-output streamer.  Does not wait:
+        a consumer makes its stream wait for the event.  Valid until the slot's next batch is submitted."""
+        p, sz, ev = ctypes.c_void_p(), ctypes.c_uint32(), ctypes.c_void_p()
+        rc = lib().BrotligStreamerDeviceOutput(self._h, ticket, index, ctypes.byref(p), ctypes.byref(sz), ctypes.byref(ev))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligStreamerDeviceOutput")
+        return p.value, sz.value, ev.value
+
+    def device_tensor(self, ticket, index, torch_stream=None):
+        """The same as a torch uint8 tensor over the streamer's device memory (no copy); torch's current stream (or `torch_stream`) is made to
+        wait for the batch's event first, so that work enqueued on it afterwards sees the decoded bytes."""
+        import torch
+        p, sz, ev = self.device_output(ticket, index)
+        s = torch_stream if torch_stream is not None else torch.cuda.current_stream()
+        rc = lib().BrotligStreamerStreamWait(self._h, ticket, ctypes.c_void_p(s.cuda_stream))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligStreamerStreamWait")
+
+        class _Mem:                                     # __cuda_array_interface__: torch wraps foreign device memory without copying
+            __cuda_array_interface__ = {"shape": (sz,), "typestr": "|u1", "data": (p, False), "version": 2}
+        return torch.as_tensor(_Mem(), device="cuda") if sz else torch.empty(0, dtype=torch.uint8, device="cuda")
+
+    def consumer_done(self, ticket, torch_stream=None):
+        """BrotligStreamerConsumerDone: everything enqueued so far on torch's current stream (or `torch_stream`) is what reads the batch; the
+        batch that reuses its slot waits for it on the device."""
+        import torch
+        s = torch_stream if torch_stream is not None else torch.cuda.current_stream()
+        rc = lib().BrotligStreamerConsumerDone(self._h, ticket, ctypes.c_void_p(s.cuda_stream))
+        if rc != BROTLIG_OK:
+            raise BrotligError(rc, "BrotligStreamerConsumerDone")
 
     def result(self, ticket):
         """Waits for the batch and returns its decoded streams as fresh arrays."""

@@ -195,3 +195,90 @@ def tile_stream(stream, repeat):
     hdr[2] = N & 0xFF
     hdr[3] = N >> 8
     return np.concatenate([hdr, new_table.view(np.uint8), np.tile(body, repeat)])
+
+
+# ---- real bytes (round 6): files that are already in the image ------------------------------------------------------
+# The reference's own sample decodes USER FILES (sample/brotlig_cli.cpp:424-446); every other workload here is synthetic.  `files(n, seed)`
+# returns n bytes read from files the ROCm image ships -- shared objects (x86 code and embedded GPU code objects), Python sources, C++
+# headers, whatever /usr/share holds (text, locale catalogues, fonts' metadata) -- in a fixed, sorted order, a few hundred KiB per file, so
+# that a 16 MiB sample already holds dozens of files of every kind.  The same image on the build container and on the GPU box gives the
+# same bytes; `files_manifest` says what they were.  Nothing is copied into the repository.
+FILE_ROOTS = (("elf", "/opt/rocm/lib", (".so",)), ("elf", "/usr/lib/x86_64-linux-gnu", (".so",)),
+              ("python", "/usr/lib/python3.10", (".py",)), ("headers", "/opt/rocm/include", (".h", ".hpp")),
+              ("share", "/usr/share", ()))
+_FILE_LISTS = {}
+
+
+def _file_list(kind_root):
+    """Sorted regular files under a root (a name filter by suffix or, for shared objects, by '.so' anywhere in the name), largest first capped:
+    at most 2 000 per root, by path order."""
+    import os
+    kind, root, suffixes = kind_root
+    if kind_root not in _FILE_LISTS:
+        found = []
+        for dirpath, dirnames, names in os.walk(root, followlinks=False):
+            dirnames.sort()
+            for name in sorted(names):
+                path = os.path.join(dirpath, name)
+                if suffixes and not (name.endswith(suffixes) or (kind == "elf" and ".so." in name)):
+                    continue
+                try:
+                    if os.path.islink(path) or not os.path.isfile(path) or os.path.getsize(path) < 4096:
+                        continue
+                except OSError:
+                    continue
+                found.append(path)
+                if len(found) >= 2000:
+                    break
+            if len(found) >= 2000:
+                break
+        _FILE_LISTS[kind_root] = found
+    return _FILE_LISTS[kind_root]
+
+
+def files(n, seed=0, chunk=384 * 1024, manifest=None):
+    """n bytes of real files: the next piece always from the root that has contributed the fewest bytes so far (shared objects are megabytes,
+    sources kilobytes: by turns they would be 85 % of the sample), the next file of that root each time (the seed picks where in each list
+    the walk starts), up to `chunk` bytes from the MIDDLE of a file (the head of a shared object is its symbol tables).  `manifest`, if a
+    list, receives (kind, path, offset, bytes) per piece."""
+    import os
+    roots = [kr for kr in FILE_ROOTS if _file_list(kr)]
+    if not roots:
+        raise RuntimeError("datagen.files: none of the file roots exists on this machine")
+    cursors = [(seed * 7919 + 13 * k) % len(_file_list(kr)) for k, kr in enumerate(roots)]
+    out, have, guard = [], 0, 0
+    given = [0] * len(roots)
+    while have < n and guard < 100000:
+        guard += 1
+        k = min(range(len(roots)), key=lambda j: (given[j], (j + seed) % len(roots)))
+        lst = _file_list(roots[k])
+        path = lst[cursors[k] % len(lst)]; cursors[k] += 1
+        try:
+            size = os.path.getsize(path)
+            take = min(chunk, size, n - have)
+            off = ((size - take) // 2) & ~4095
+            with open(path, "rb") as f:
+                f.seek(off)
+                b = np.frombuffer(f.read(take), dtype=np.uint8)
+        except OSError:
+            continue
+        if len(b) == 0:
+            continue
+        out.append(b); have += len(b); given[k] += len(b)
+        if manifest is not None:
+            manifest.append((roots[k][0], path, int(off), int(len(b))))
+    if have < n:
+        raise RuntimeError("datagen.files: not enough readable bytes")
+    return np.concatenate(out)[:n].copy()
+
+
+def files_manifest_summary(manifest):
+    """{kind: {"pieces", "bytes"}} plus a SHA-256 over the (path, offset, bytes) list: what a `files` sample was made of."""
+    import hashlib
+    by = {}
+    h = hashlib.sha256()
+    for kind, path, off, nb in manifest:
+        d = by.setdefault(kind, {"pieces": 0, "bytes": 0})
+        d["pieces"] += 1; d["bytes"] += nb
+        h.update(f"{path}:{off}:{nb}\n".encode())
+    return {"kinds": by, "pieces": len(manifest), "list_sha16": h.hexdigest()[:16]}

@@ -251,6 +251,33 @@ const uint8_t* BrotligStreamerOutput(BrotligStreamer* streamer, uint64_t ticket,
  * displaced). */
 BROTLIG_ERROR BrotligStreamerStreamResult(BrotligStreamer* streamer, uint64_t ticket, uint32_t index);
 
+/* Round 6: DEVICE-OUTPUT mode -- the consumer of the reference's GPU path is on the GPU (the shader's `output` UAV is what the renderer reads,
+ * src/decoder/BrotliGCompute.hlsl:93-95; the sample only copies it back to compare, sample/BrotligGPUDecoder.cpp:635-675).  A streamer created
+ * with BrotligStreamerCreateDeviceOutput downloads nothing but the status words and allocates no pinned staging for decoded bytes: Submit
+ * (with outputs == NULL) uploads the compressed streams and enqueues the decode; BrotligStreamerDeviceOutput then hands back, WITHOUT
+ * waiting, where stream `index` of the batch will be -- device pointer, size, and the hipEvent_t recorded behind the batch's kernels.  A
+ * consumer enqueues hipStreamWaitEvent(its stream, event) and reads; when its work on the batch is enqueued it calls
+ * BrotligStreamerConsumerDone(streamer, ticket, its stream), and the batch that reuses the slot (num_slots submissions later) waits for
+ * that point on the device.  The pointers stay valid until that batch is submitted.  Results per batch and per stream as in host mode
+ * (Wait / StreamResult: a damaged stream's bytes are undefined, the others are good); BrotligStreamerOutput returns NULL in this mode. */
+BROTLIG_ERROR BrotligStreamerCreateDeviceOutput(uint32_t num_slots, uint64_t slot_in_bytes, uint64_t slot_out_bytes,
+                                                uint32_t max_streams_per_batch, BrotligStreamer** out);
+BROTLIG_ERROR BrotligStreamerDeviceOutput(BrotligStreamer* streamer, uint64_t ticket, uint32_t index,
+                                          void** d_ptr, uint32_t* size, void** hip_event);
+/* the same wait for a caller that does not handle HIP events itself: everything enqueued on `hip_stream` after this call sees the batch decoded */
+BROTLIG_ERROR BrotligStreamerStreamWait(BrotligStreamer* streamer, uint64_t ticket, void* hip_stream);
+BROTLIG_ERROR BrotligStreamerConsumerDone(BrotligStreamer* streamer, uint64_t ticket, void* hip_stream);
+
+/* Round 6: the compressed bytes written where the upload reads them.  Submit copies every stream into pinned memory first (one host thread:
+ * ~5 ms for a 54 MiB batch whose upload takes 1 ms and whose decode 0.5).  A loader that READS its streams -- from disk, from a network -- can
+ * read them straight into that memory: Acquire hands out the staging area of the slot the next batch goes to (completing the batch the slot
+ * still holds, exactly as Submit would), the caller places its streams there at 16-byte aligned, ascending offsets, and SubmitInPlace
+ * validates the headers where they lie and enqueues upload and decode.  A refused SubmitInPlace leaves the area acquired (repair and retry);
+ * between Acquire and a successful SubmitInPlace no other Submit is accepted.  Either mode (host or device output). */
+BROTLIG_ERROR BrotligStreamerAcquire(BrotligStreamer* streamer, uint8_t** staging, uint64_t* capacity);
+BROTLIG_ERROR BrotligStreamerSubmitInPlace(BrotligStreamer* streamer, uint32_t num_streams, const uint64_t* offsets, const uint32_t* input_sizes,
+                                           uint8_t* const* outputs, const uint32_t* output_caps, uint64_t* ticket);
+
 /* Diagnostics, for tests.  Both switches below are INERT unless the process was started with BROTLIG_ENABLE_DEBUG_KNOBS=1 in its
  * environment (read once; BrotligDebugKnobsEnabled() answers): a production process cannot have its kernel selection changed by a stray
  * call or a forgotten reset.

@@ -32,4 +32,70 @@ for slots in (1, 3):
     res[f"slots_{slots}"] = {"seconds": round(dt, 4), "decoded_GBps": round(batches * u_bytes / dt / 1e9, 2),
                              "compressed_in_GBps": round(batches * c_bytes / dt / 1e9, 2)}
     st.close()
+# Round 6: device-output mode -- nothing but the compressed bytes crosses PCIe; a consumer on its own stream reads every batch on the device
+# (a checksum kernel over the decoded bytes) and hands the slot back
+import torch
+for slots in (1, 3):
+    st = api.Streamer(slots=slots, slot_in_bytes=c_bytes + (1 << 20), slot_out_bytes=u_bytes + (1 << 20), max_streams=spb, device_output=True)
+    consumer = torch.cuda.Stream()
+    t = st.submit(streams)
+    for i, e in enumerate(expected):                                # warm-up + correctness
+        o = st.device_tensor(t, i).cpu().numpy()
+        assert o.size % e.size == 0 and np.array_equal(o.reshape(-1, e.size), np.broadcast_to(e, (o.size // e.size, e.size)))
+    st.wait(t)
+    sums = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tickets = []
+    for b in range(batches):
+        tk = st.submit(streams)
+        tickets.append(tk)
+        with torch.cuda.stream(consumer):
+            sums.append(sum(st.device_tensor(tk, i).view(torch.int64 if st.device_output(tk, i)[1] % 8 == 0 else torch.uint8).sum() for i in range(spb)))
+            st.consumer_done(tk)
+    for tk in tickets[-slots:]:
+        st.wait(tk)
+    consumer.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(int(x) == int(sums[0]) for x in sums)
+    res[f"device_out_slots_{slots}"] = {"seconds": round(dt, 4), "decoded_GBps": round(batches * u_bytes / dt / 1e9, 2),
+                                        "compressed_in_GBps": round(batches * c_bytes / dt / 1e9, 2)}
+    st.close()
+# ... and with the compressed streams already IN the slot's pinned staging area (BrotligStreamerAcquire / SubmitInPlace: where a file read
+# leaves them) instead of copied there by Submit -- one host thread, 5 ms per 54 MiB batch, more than upload and decode together
+for slots in (3,):
+    st = api.Streamer(slots=slots, slot_in_bytes=c_bytes + (1 << 20), slot_out_bytes=u_bytes + (1 << 20), max_streams=spb, device_output=True)
+    consumer = torch.cuda.Stream()
+    offs, pos = [], 0
+    for s_ in streams:
+        offs.append(pos); pos = (pos + len(s_) + 15) // 16 * 16
+    szs = [len(s_) for s_ in streams]
+    for _ in range(slots):                                          # every slot's staging area filled once: the bytes stay where they are
+        area = st.acquire()
+        for o, s_ in zip(offs, streams):
+            area[o:o + len(s_)] = s_
+        tk = st.submit_in_place(offs, szs)
+    for i, e in enumerate(expected):
+        o = st.device_tensor(tk, i).cpu().numpy()
+        assert o.size % e.size == 0 and np.array_equal(o.reshape(-1, e.size), np.broadcast_to(e, (o.size // e.size, e.size)))
+    st.wait(tk)
+    torch.cuda.synchronize()
+    sums, tickets = [], []
+    t0 = time.perf_counter()
+    for b in range(batches):
+        st.acquire()                                                # (the "read" has happened: the area holds the streams)
+        tk = st.submit_in_place(offs, szs)
+        tickets.append(tk)
+        with torch.cuda.stream(consumer):
+            sums.append(sum(st.device_tensor(tk, i).view(torch.int64 if st.device_output(tk, i)[1] % 8 == 0 else torch.uint8).sum() for i in range(spb)))
+            st.consumer_done(tk)
+    for tk in tickets[-slots:]:
+        st.wait(tk)
+    consumer.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(int(x) == int(sums[0]) for x in sums)
+    res[f"device_out_in_place_slots_{slots}"] = {"seconds": round(dt, 4), "decoded_GBps": round(batches * u_bytes / dt / 1e9, 2),
+                                                 "compressed_in_GBps": round(batches * c_bytes / dt / 1e9, 2),
+                                                 "what": "streams already in the pinned staging area (as a file read leaves them): upload + decode + a consumer kernel per batch"}
+    st.close()
 print(json.dumps(res))

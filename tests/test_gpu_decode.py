@@ -374,6 +374,114 @@ def test_page_schedule_large_batch(api):
 
 
 @pytest.mark.gpu
+def test_streamer_device_output_mode(api):
+    """Round 6: a streamer whose decoded bytes STAY in device memory -- no download, no pinned staging for them.  Seven
+    batches of mixed plain and pre-conditioned streams through a 2-slot ring (more batches than slots), one of them with a damaged stream: every
+    stream is handed back as {device pointer, size, event} straight after Submit, a consumer on its own torch stream waits for the event and
+    copies the bytes aside (its hand-back, BrotligStreamerConsumerDone, is what the slot's next batch waits for on the device); afterwards
+    every byte is compared with the oracle and the damaged stream is named."""
+    import torch
+    from fuzzcases import simple_code_one_symbol
+    bad, cap = simple_code_one_symbol()
+    batches, wants = [], []
+    for b in range(7):
+        datas = [D.mixed(65536 * 3 + 1000 * b, 100 + b), D.text(40000 + b, 200 + b), D.runs(65536 * 2, 300 + b)]
+        streams = [E.encode(d) for d in datas]
+        tex = D.bc_texture(1 + b % 5, 64, 32, seed=b)
+        streams.append(E.encode(tex, precondition=dict(format=1 + b % 5, width_blocks=64, height_blocks=32, swizzle=True, delta=True)))
+        want = []
+        for s_, d in zip(streams, datas + [tex]):
+            rc, ref = oracle_decode(s_, out_size=len(d))
+            assert rc == 0
+            want.append(ref)
+        if b == 4:
+            streams.insert(1, bad); want.insert(1, None)
+        batches.append(streams); wants.append(want)
+    st = api.Streamer(slots=2, slot_in_bytes=4 << 20, slot_out_bytes=8 << 20, max_streams=16, device_output=True)
+    with pytest.raises(api.BrotligError):               # nothing is downloaded in this mode: caller buffers are refused
+        st.submit(batches[0], [np.zeros(api.DecompressedSize(s_), np.uint8) for s_ in batches[0]])
+    consumer = torch.cuda.Stream()
+    kept, tickets = [], []
+    for k, streams in enumerate(batches):
+        t = st.submit(streams)                          # (with both slots in flight this completes the oldest batch first)
+        tickets.append(t)
+        with torch.cuda.stream(consumer):
+            copies = []
+            for i in range(len(streams)):
+                ten = st.device_tensor(t, i)            # makes `consumer` wait for the batch's event
+                copies.append(ten.clone())
+            st.consumer_done(t)
+        kept.append(copies)
+        assert st.output(t, 0) is None                  # no host copy exists
+    for k, (t, want) in enumerate(zip(tickets, wants)):
+        if k >= len(tickets) - 2:                       # the last two batches are still in their slots
+            if k == 4:
+                with pytest.raises(api.BrotligError):
+                    st.wait(t)
+            else:
+                st.wait(t)
+    assert st.stream_results(tickets[-1], len(batches[-1])) == [api.BROTLIG_OK] * len(batches[-1])
+    consumer.synchronize()
+    for k, (copies, want) in enumerate(zip(kept, wants)):
+        for i, (c, w) in enumerate(zip(copies, want)):
+            if w is not None:
+                assert np.array_equal(c.cpu().numpy(), w), (k, i)
+    st.close()
+    # the damaged stream is named while its batch is still in its slot
+    st = api.Streamer(slots=2, slot_in_bytes=4 << 20, slot_out_bytes=8 << 20, max_streams=16, device_output=True)
+    t = st.submit(batches[4])
+    with pytest.raises(api.BrotligError):
+        st.wait(t)
+    res = st.stream_results(t, len(batches[4]))
+    assert res[1] == api.BROTLIG_ERROR_GENERIC and all(r == api.BROTLIG_OK for i, r in enumerate(res) if i != 1)
+    for i, w in enumerate(wants[4]):
+        if w is not None:
+            assert np.array_equal(st.device_tensor(t, i).cpu().numpy(), w), i
+    st.close()
+
+
+@pytest.mark.parametrize("device_output", [False, True], ids=["host_output", "device_output"])
+def test_streamer_streams_written_in_place(api, device_output):
+    """Round 6: BrotligStreamerAcquire / SubmitInPlace -- the compressed streams are written straight into the slot's pinned staging area (what a
+    file read does) instead of being copied there by Submit.  Five batches through two slots, both output modes; a batch with a bad offset and
+    one with a damaged header are refused and leave the area acquired; an ordinary Submit is refused while an area is out."""
+    st = api.Streamer(slots=2, slot_in_bytes=2 << 20, slot_out_bytes=4 << 20, max_streams=8, device_output=device_output)
+    tickets, wants = [], []
+    for b in range(5):
+        datas = [D.mixed(65536 + 999 * b, 40 + b), D.text(30000 + b, 50 + b), D.runs(70000, 60 + b)]
+        streams = [E.encode(d) for d in datas]
+        area = st.acquire()
+        offs, pos = [], 0
+        for s_ in streams:
+            offs.append(pos); area[pos:pos + len(s_)] = s_; pos = (pos + len(s_) + 15) // 16 * 16
+        if b == 1:
+            with pytest.raises(api.BrotligError):
+                st.submit(streams)                                  # an area is out: the ordinary Submit waits its turn
+            with pytest.raises(api.BrotligError):
+                st.submit_in_place([offs[0] + 4] + offs[1:], [len(s_) for s_ in streams])      # not 16-byte aligned
+            keep = area[1]; area[1] ^= 0x10
+            with pytest.raises(api.BrotligError):
+                st.submit_in_place(offs, [len(s_) for s_ in streams])                           # damaged magic: refused, still acquired
+            area[1] = keep
+        outs = None if (device_output or b % 2) else [np.full(len(d), 0xAB, np.uint8) for d in datas]
+        tickets.append((st.submit_in_place(offs, [len(s_) for s_ in streams], outs), outs)); wants.append(datas)
+        if b >= 1:
+            t, o = tickets[b - 1]
+            if device_output:
+                got = [st.device_tensor(t, i).cpu().numpy() for i in range(3)]
+                st.consumer_done(t)
+                st.wait(t)
+            else:
+                got = st.result(t)
+            for g, w in zip(got, wants[b - 1]):
+                assert np.array_equal(g, w), b
+    t, o = tickets[-1]
+    got = [st.device_tensor(t, i).cpu().numpy() for i in range(3)] if device_output else st.result(t)
+    for g, w in zip(got, wants[-1]):
+        assert np.array_equal(g, w)
+    st.close()
+
+
 def test_streamer_ring_overflow_keeps_results(api):
     """More batches submitted than there are slots before anything is waited for: Submit completes the oldest
     batch to make room, fills its outputs[] and keeps its result for a later Wait.  A refused batch

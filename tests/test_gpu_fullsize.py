@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pytest
 
+from brotli_g_sdk_amd import datagen as D
+from brotli_g_sdk_amd import encoder as E
 from helpers import ROOT, oracle_decode
 
 pytestmark = pytest.mark.gpu
@@ -148,3 +150,26 @@ def test_config5_32gib_eight_shards_on_the_one_device(api):
     # shards are balanced by compressed bytes: none carries more than 1.25 x its share
     assert r["shard_imbalance_compressed"] < 1.25, r["shard_imbalance_compressed"]
     assert "projection" in r["label"] and r["projected_GBps_kernel"] > r["one_device_GBps_kernel"]
+
+
+def test_real_files_sample_against_the_oracle(api):
+    """Round 6: not one real file had been through the GPU path.  32 MiB read from files the image ships (shared objects,
+    Python sources, C++ headers, /usr/share: datagen.files) as four streams under the default parse, 2 MiB of the same under the optimal parse
+    with the distance-parameter search (what the reference's encoder resembles more): every byte against the source and against the oracle."""
+    manifest = []
+    datas = [D.files(8 << 20, seed, manifest=manifest) for seed in range(4)]
+    kinds = D.files_manifest_summary(manifest)["kinds"]
+    assert len(kinds) >= 3 and all(v["bytes"] > (1 << 20) for v in kinds.values()), kinds
+    streams = [E.encode(d) for d in datas]
+    small = datas[0][:2 << 20]
+    streams.append(E.encode(small, flags=E.OPTIMAL_PARSE | E.SEARCH_DIST_PARAMS))
+    datas.append(small)
+    dec = api.BatchDecoder(streams)
+    dec.poison_output()
+    dec.decode()
+    for i, (d, s) in enumerate(zip(datas, streams)):
+        out = dec.output(i)
+        assert np.array_equal(out, d), i
+        if i in (0, 4):
+            rc, ref = oracle_decode(s)
+            assert rc == 0 and np.array_equal(ref, out), i
