@@ -172,6 +172,25 @@ def round_loop_scratch(co, kernel="brotlig_decode_kernel"):
     return out
 
 
+def loops_scratch(co, kernel, min_insts=400):
+    """Scratch accesses inside ANY natural loop of at least `min_insts` instructions of a kernel that holds no global atomic (a page loop
+    takes pages from a counter; a few reloads per PAGE are tolerated): [(loop start, loop end, instructions, [(address, opcode), ...])].  For
+    kernels whose round loops carry no s_setprio mark (the two-wavefront kernel)."""
+    sym, start, _ = kernel_symbol(co, kernel)
+    insts = disassemble(co, sym)
+    loops = set()
+    for i in insts:
+        if i["op"].startswith(("s_cbranch", "s_branch")) and i["label"] is not None and start + i["label"] <= i["addr"]:
+            loops.add((start + i["label"], i["addr"]))
+    out = []
+    for lo, hi in sorted(loops):
+        body = [i for i in insts if lo <= i["addr"] <= hi]
+        if len(body) < min_insts or any(i["op"].startswith(("global_atomic", "flat_atomic")) for i in body):
+            continue
+        out.append((hex(lo - start), hex(hi - start), len(body), [(hex(i["addr"] - start), i["op"]) for i in body if i["op"].startswith("scratch_")]))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kernel", default="brotlig_decode_kernel")

@@ -39,6 +39,11 @@ def test_small_batch_and_deconditioning_kernels_do_not_spill():
     sym, start, size = isa_budget.kernel_symbol(co, "brotlig_decode_duo_kernel")
     scratch = [i["op"] for i in isa_budget.disassemble(co, sym) if i["op"].startswith("scratch_")]
     assert len(scratch) <= 8, ("brotlig_decode_duo_kernel", scratch)
+    # ... and WHERE they sit: none inside a round of either wavefront -- the loops of a few hundred instructions and more that take no
+    # page from the counter are the producer's and the consumer's round and group loops
+    loops = isa_budget.loops_scratch(co, "brotlig_decode_duo_kernel")
+    assert len(loops) >= 2, loops
+    assert not [l for l in loops if l[3]], [l for l in loops if l[3]]
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles gfx950 without a GPU)")

@@ -255,7 +255,7 @@ def test_sim_schedule_kernel_many_streams_by_tickets(sim):
         for workers in (1, 4):
             sim.sim_set_schedule(workers, 1)
             outs, status = run_batch(sim, streams, [len(d) for d in datas], grid=6)
-            assert sim.sim_last_schedule_grid() == 4 + 1 + 1 + 2 * workers           # 4 chunks, scan, one finalize item, workers
+            assert sim.sim_last_schedule_grid() == 1 + 1 + 1 + 2 * workers           # 4 chunks in one prepare item, scan, one finalize item, workers
             assert status == 1 and [i for i in range(200) if sim.sim_stream_status(i)] == [77]
             for i, (o, d) in enumerate(zip(outs, datas)):
                 if i != 77:
