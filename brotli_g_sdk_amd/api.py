@@ -375,19 +375,26 @@ class BatchDecoder:
                 if rc != BROTLIG_OK:
                     raise BrotligError(rc, "BrotligDecodeBatchStatus")
 
-    def timed(self, warmup, steps):
+    def timed(self, warmup, steps, check=True):
         """Returns (total_ms over `steps` passes, average decode-kernel ms), both from HIP events on
-        the launch stream."""
+        the launch stream.  check=False leaves the batch status to the caller (status(): a copy and a wait that a caller timing the
+        steps with its own clock does after its clock has stopped)."""
         with self.torch.cuda.device(self.device):
             st = self._stream()
             total, kern = ctypes.c_double(0.0), ctypes.c_double(0.0)
             rc = lib().BrotligDecodeBatchTimed(*self._args(st), warmup, steps, ctypes.byref(total), ctypes.byref(kern))
             if rc != BROTLIG_OK:
                 raise BrotligError(rc, "BrotligDecodeBatchTimed")
-            rc = lib().BrotligDecodeBatchStatus(self.d_ws.data_ptr(), st)
+            if check:
+                self.status()
+            return total.value, kern.value
+
+    def status(self):
+        """BrotligDecodeBatchStatus of the last decode (waits for the stream); raises on a failed batch."""
+        with self.torch.cuda.device(self.device):
+            rc = lib().BrotligDecodeBatchStatus(self.d_ws.data_ptr(), self._stream())
             if rc != BROTLIG_OK:
                 raise BrotligError(rc, "BrotligDecodeBatchStatus")
-            return total.value, kern.value
 
     def stream_status(self):
         """BrotligDecodeBatchStreamStatus: (batch result, [BROTLIG_ERROR per stream]) of the last decode -- which assets were damaged."""

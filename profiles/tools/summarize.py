@@ -9,12 +9,12 @@ src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 pre = os.path.join(dst, f"r{rnd}_{tag}_")
 
-for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16", "bench_records", "bench_distinct4096", "latency", "streamer_bench", "cpu_decode", "config5_projection"):
+for name in ("bench", "bench_bc3", "bench_runs", "bench_text", "bench_samples16", "bench_records", "bench_distinct4096", "bench_files", "bench_files_optimal_parse", "latency", "streamer_bench", "cpu_decode", "config5_projection"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, pre + name + ".json")
 shutil.copy(os.path.join(src, "phase_profile.jsonl"), pre + "phase_profile.jsonl")
-for extra in ("page_latency.jsonl", "wave_times.jsonl"):
+for extra in ("page_latency.jsonl", "wave_times.jsonl", "sched_times.jsonl", "many_streams.jsonl", "many_textures.jsonl"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), pre + extra)
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
@@ -111,5 +111,19 @@ if sq:
             f.write("\nPipe occupancy (quad-cycles / (cycles x 256 CUs)): vector ALU %.3f, scalar %.3f, LDS %.3f; active lanes per vector instruction %.3f\n" % (
                 sq["SQ_ACTIVE_INST_VALU"] / cu_cycles, sq.get("SQ_ACTIVE_INST_SCA", 0) / cu_cycles, sq.get("SQ_ACTIVE_INST_LDS", 0) / cu_cycles,
                 sq.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * sq["SQ_ACTIVE_INST_VALU"])))
+# round 6: instruction cache of the decode kernel (70 KB of code against 64 KB of cache), and the L2 counters with every page distinct
+extra = {}
+for sub in ("pmc_icache", "pmc_tcc_distinct4096"):
+    ps = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    if not ps: continue
+    acc = {}
+    for r in csv.DictReader(open(ps[0])):
+        if "brotlig_decode_kernel" in r["Kernel_Name"]:
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    extra[sub] = {k: sum(v) / len(v) for k, v in acc.items()}
+if extra:
+    if "pmc_icache" in extra and extra["pmc_icache"].get("SQC_ICACHE_REQ"):
+        ic = extra["pmc_icache"]; ic["hit_rate"] = ic.get("SQC_ICACHE_HITS", 0) / ic["SQC_ICACHE_REQ"]
+    json.dump(extra, open(pre + "pmc_icache_and_tcc_distinct.json", "w"), indent=1)
 print(json.dumps({"decode_ms_rocprof": dec_avg, "decode_ms_bench": bench["roofline"]["kernel_ms"],
                   "fetch_GB": fetch * 1024 / 1e9, "write_GB": write * 1024 / 1e9, "alg_GB": alg / 1e9}))
