@@ -482,6 +482,54 @@ def test_streamer_streams_written_in_place(api, device_output):
     st.close()
 
 
+def test_schedule_kernel_in_garbage_and_reused_workspaces(api):
+    """Round 6: the one kernel in front of the page decode needs no memset -- it initialises a workspace it has never seen (garbage where its
+    cookie, tickets and counters live: one workgroup wins the right to zero them, the others wait for it) and leaves its words clean for the
+    next launch.  A batch on the ticket path (80 streams: prepare, scan, finalize, count, scatter items) and one on the one-workgroup path, each
+    in a workspace of random bytes, then again in the same workspace, then in a workspace that holds what ANOTHER batch of another shape left
+    behind (header words copied over); every stream bit-exact, the damaged one named, every time."""
+    import torch
+    from fuzzcases import simple_code_one_symbol
+    bad, cap = simple_code_one_symbol()
+    rng = np.random.default_rng(61)
+    makers = [D.text, D.records, D.samples16, D.runs, D.mixed, D.random_bytes]
+    big_d = [makers[i % 6](int(rng.integers(1, 3 * 65536)), 7000 + i) for i in range(80)]
+    big_s = [E.encode(d) for d in big_d]
+    big_s[17] = bad
+    sizes = [len(d) for d in big_d]; sizes[17] = cap
+    small_d = [D.mixed(5 * 65536 + 77, 1), D.text(65536, 2), D.runs(2 * 65536, 3)]
+    small_s = [E.encode(d) for d in small_d]
+    decs = {"big": api.BatchDecoder(big_s, out_sizes=sizes), "small": api.BatchDecoder(small_s)}
+
+    def check(name):
+        dec = decs[name]
+        dec.poison_output()
+        if name == "big":
+            with pytest.raises(api.BrotligError):
+                dec.decode()
+            rc, per = dec.stream_status()
+            assert [i for i, r in enumerate(per) if r != api.BROTLIG_OK] == [17]
+            for i, d in enumerate(big_d):
+                if i != 17:
+                    assert np.array_equal(dec.output(i), d), i
+        else:
+            dec.decode()
+            for i, d in enumerate(small_d):
+                assert np.array_equal(dec.output(i), d), i
+
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    for name in ("big", "small"):
+        dec = decs[name]
+        dec.d_ws.copy_(torch.randint(0, 256, (dec.ws_bytes,), dtype=torch.uint8, device="cuda", generator=g))     # a workspace nobody has zeroed
+        check(name)
+        check(name)                                     # the same workspace again: what the first launch left
+    # what another batch of another shape left behind: the header words (status, counters, the schedule kernel's own) of the other workspace
+    hdr = 192 * 4
+    a, b = decs["big"].d_ws[:hdr].clone(), decs["small"].d_ws[:hdr].clone()
+    decs["big"].d_ws[:hdr].copy_(b); decs["small"].d_ws[:hdr].copy_(a)
+    check("big"); check("small"); check("big")
+
+
 def test_streamer_ring_overflow_keeps_results(api):
     """More batches submitted than there are slots before anything is waited for: Submit completes the oldest
     batch to make room, fills its outputs[] and keeps its result for a later Wait.  A refused batch
