@@ -235,6 +235,8 @@ def main():
                     help=".npz of streams made by profiles/tools/preencode.py with the same workload / distinct / flags")
     ap.add_argument("--no-alt-parse", action="store_true",
                     help="skip the second measurement on the same pages encoded with the optimal parse (reported as \"alt\", outside `value`)")
+    ap.add_argument("--two-in-flight", action="store_true",
+                    help="also measure two batches in flight on two HIP streams (reported as \"two_batches_in_flight\", outside `value`; 5 GiB more device memory)")
     ap.add_argument("--stack-ranks", action="store_true",
                     help="launch-path test only: ranks beyond the visible devices share them (gloo control plane, "
                          "labelled \"stacked\" in the output; not a scaling measurement)")
@@ -378,6 +380,33 @@ def main():
         roof_ms = shard.max_over_ranks(total_ms / args.steps)
     achieved = roof_bytes / (roof_ms * 1e-3) / 1e9
 
+    # Two batches in flight (round 6; reported beside `value`, never instead of it): the same streams in a second set of buffers, the steps
+    # enqueued in turn on two HIP streams.  One batch at a time leaves 4 % of the wavefront-time idle while the last pages of a launch finish
+    # (half a pair of pages per wavefront, inherent to 8 pages per half-wave); the next batch's schedule kernel and first pages
+    # fill that -- what a streaming caller (BrotligStreamer*: three slots) gets.
+    overlap = None
+    if args.two_in_flight and world == 1 and args.workload != "bc3":
+        dec_b = api.BatchDecoder(streams, device=dev)
+        s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+        for d_, st_ in ((dec, s_a), (dec_b, s_b)):
+            with torch.cuda.stream(st_):
+                d_.decode(check=False)
+        torch.cuda.synchronize()
+        n2 = 2 * max(args.steps, 5)
+        t2 = time.perf_counter()
+        for k in range(n2):
+            with torch.cuda.stream(s_a if k % 2 == 0 else s_b):
+                (dec if k % 2 == 0 else dec_b).decode(check=False)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t2
+        dec_b.status(); dec.status()
+        ok_b = all(bool((dec_b.d_out[dec_b.out_offs[k]:dec_b.out_offs[k] + dec_b.sizes[k]].view(-1, len(expected[k]))
+                         == torch.from_numpy(expected[k]).to(dev).unsqueeze(0)).all()) for k in range(len(streams)))
+        overlap = {"what": "two batches in flight on two HIP streams (second set of buffers and workspace), steps enqueued in turn",
+                   "value": round(n2 * per_rank_u / t2 / 1e9, 3), "unit": "GB/s", "steps": n2, "ms_per_step": round(t2 / n2 * 1e3, 4), "bit_exact": ok_b}
+        del dec_b
+        torch.cuda.empty_cache()
+
     # The same pages under the encoder's densest parse (shortest-path parse + distance parameter search): what the
     # reference's Zopfli-based encoder (src/encoder/PageEncoder.cpp:87-147) produces resembles it more than the
     # default lazy parse does.  Reported beside `value`, never instead of it.
@@ -433,6 +462,8 @@ def main():
             line["config"]["files"] = D.files_manifest_summary(FILES_MANIFEST[:len(FILES_MANIFEST) // (2 if alt is not None else 1)])
         if alt is not None:
             line["alt"] = alt
+        if overlap is not None:
+            line["two_batches_in_flight"] = overlap
         if world > 1:
             line["ranks"] = {"world_size": world, "backend": "gloo" if stacked else "nccl (RCCL)", "stacked": bool(stacked),
                              "ranks_that_decoded": int(decoded_ranks)}
