@@ -65,7 +65,7 @@ __device__ inline void duo_producer(DuoLds& D, const DecodeArgs& a)
     PageJob job = no_job(a);
     bool live = false, finished = lane >= 32u, bad = false;
     BitReader br;
-    br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
+    br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero(); br.slot = nullptr; br.slot0 = 0;
     DistanceRing ring;
     uint32_t out_pos = 0, prev_tail = 0, carry_head = 0;
     uint32_t k = 0;                                                     // steps produced so far

@@ -286,6 +286,9 @@ static_assert(kWin + 16 >= kIcpAlphabet, "the window holds the code lengths duri
 struct __attribute__((aligned(16))) WaveLds {
     PageLds  page[2];
     uint32_t len_code_tab[48];
+#if BROTLIG_EXP_GLDS
+    uint8_t  glds[64 * 16] __attribute__((aligned(16)));   // (experiment builds only: a 16-byte slot per lane for the bit readers)
+#endif
 };
 // the one-page layout lives in the same storage (decode_kernel_body); len_code_tab stays where it is
 static_assert(sizeof(PageLdsSolo) <= 2 * sizeof(PageLds), "the one-page record must fit the LDS of the two halves");
@@ -306,7 +309,15 @@ __device__ __forceinline__ void store16(uint8_t* p, Bytes16 v) { *reinterpret_ca
 // stream needs is ever cut short; a reader that has run away on a corrupt stream is held at the last 8
 // readable bytes (`limit8`) and decodes whatever is there (the reference over-reads unchecked,
 // inc/common/BrotligDeswizzler.h:74-81).
-struct BitReader {
+// (BROTLIG_EXP_GLDS, an experiment of round 6 -- profiles/r06_traffic.md -- never the product: 1 = the reader's 8 bytes "in flight" in two
+// registers become 16 bytes in an LDS slot of the lane's own, filled by CDNA4's direct global -> LDS load (global_load_lds_dwordx4: no
+// register, and half as many trips to a 128-byte line of the input); 2 = the control: the register reader with the same 1 KiB more LDS per
+// wavefront, i.e. the same 14 workgroups per compute unit.)
+#ifndef BROTLIG_EXP_GLDS
+#define BROTLIG_EXP_GLDS 0
+#endif
+template <bool kGlds>
+struct BitReaderT {
     const uint8_t* base;    // page start in the input buffer
     uint32_t limit8;        // last byte offset from base at which 8 bytes may be loaded
     uint64_t buf;
@@ -314,21 +325,38 @@ struct BitReader {
     uint32_t next;          // byte offset of the next 8-byte load, dword aligned relative to base
     uint64_t queue;
     uint32_t queued;        // 0, 32 or 64
-    uint64_t flight;        // the 8 bytes loaded last, not waited for until they are needed
+    uint64_t flight;        // the 8 bytes loaded last, not waited for until they are needed (kGlds: bit 0 = which half of the slot is next)
     uint32_t zero;          // wave::opaque_zero()
+    uint8_t* slot;          // kGlds: this lane's 16 bytes of LDS; the wavefront's 64 slots lie back to back from slot0
+    uint32_t slot0;         // kGlds: LDS byte address of lane 0's slot (wave-uniform: the direct load's M0)
 
     // Issues the 8-byte load for byte offset `rel` without touching its result.  Branch-free on purpose: a
     // conditional load would reach `flight` through a register copy, and the copy would wait for the load
     // just issued.
     __device__ __forceinline__ uint64_t load8(uint32_t rel) const { return load_u64u_g(base + min_rel(rel)); }
     __device__ __forceinline__ uint32_t min_rel(uint32_t rel) const { return rel < limit8 ? rel : limit8; }
+    // kGlds: 16 bytes from byte offset `rel` (held at the last 16 readable bytes) straight into this lane's slot; not waited for
+    __device__ __forceinline__ void dma16(uint32_t rel) const
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && BROTLIG_EXP_GLDS == 1
+        const uint32_t lim16 = limit8 >= 8u ? limit8 - 8u : 0u;
+        const uint8_t* src = base + (rel < lim16 ? rel : lim16);
+        uint32_t keep;
+        // (every LDS read of the slot has returned before the load that overwrites it is issued: lgkmcnt(0))
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(slot0) : "memory");
+#else
+        (void)rel;
+#endif
+    }
     __device__ __forceinline__ void init(const uint8_t* b, uint32_t lim, uint32_t start)
     {
         base = b; limit8 = lim >= 8u ? lim - 8u : 0u; zero = wave::opaque_zero();
         const uint32_t a = start & ~3u, skip = (start & 3u) * 8u;
         const uint64_t first = load8(a);
         next = a + 8u;
-        flight = load8(next); next += 8u;
+        if constexpr (kGlds) { dma16(next); next += 16u; flight = 0; }
+        else { flight = load8(next); next += 8u; }
         buf = (uint64_t)((uint32_t)first >> skip);
         avail = 32u - skip;
         queue = first >> 32; queued = 32u;
@@ -338,7 +366,22 @@ struct BitReader {
     {
         // `flight >> zero` rather than a copy: with a plain copy the compiler keeps the old pair where it is, loads
         // the new one into a scratch pair and copies it over -- and that copy waits for the load just issued
-        if (queued == 0u) { queue = flight >> zero; queued = 64u; flight = load8(next); next += 8u; }
+        if (queued == 0u) {
+            if constexpr (kGlds) {
+#if defined(__HIP_DEVICE_COMPILE__) && BROTLIG_EXP_GLDS == 1
+                if ((uint32_t)flight == 0u) {           // the slot's first half: the direct load has to have landed
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    queue = *reinterpret_cast<const volatile uint64_t*>(slot);
+                    flight = 1;
+                } else {                                // its second half, then the next 16 bytes on their way
+                    queue = *reinterpret_cast<const volatile uint64_t*>(slot + 8);
+                    flight = 0;
+                    dma16(next); next += 16u;
+                }
+#endif
+                queued = 64u;
+            } else { queue = flight >> zero; queued = 64u; flight = load8(next); next += 8u; }
+        }
         buf |= (uint64_t)(uint32_t)queue << avail;
         queue >>= 32; queued -= 32u;
         avail += 32u;
@@ -358,6 +401,7 @@ struct BitReader {
         return v;
     }
 };
+typedef BitReaderT<false> BitReader;
 
 __device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t bit_width_u32(uint32_t x) { return x ? 32u - (uint32_t)__clz((int)x) : 0u; }

@@ -287,8 +287,13 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
     // and helps with long copies instead.  A template parameter, not a flag: the two-page instantiation is compiled without it.
     constexpr bool solo = kSolo;
     bool finished = lane >= 32u && solo;    // the work counter ran out for this half (or it sits this launch out)
-    BitReader br;
+    BitReaderT<(BROTLIG_EXP_GLDS == 1)> br;
     br.base = a.in; br.limit8 = 0; br.buf = 0; br.avail = 64; br.next = 0; br.queue = 0; br.queued = 64; br.flight = 0; br.zero = wave::opaque_zero();
+    br.slot = nullptr; br.slot0 = 0;
+#if BROTLIG_EXP_GLDS
+    br.slot = W.glds + 16u * lane;
+    br.slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)W.glds);      // (LDS addresses are the low 32 bits of the generic ones)
+#endif
     DistanceRing ring;
     uint32_t out_pos = 0;            // bytes of the page produced so far
     uint32_t prev_tail = 0;          // literals decoded but not yet consumed
