@@ -201,7 +201,7 @@ template <uint32_t kSizes, uint32_t kNumSub>
 __device__ __forceinline__ uint32_t dc_texture(const DcTable* __restrict__ tp, const uint8_t* __restrict__ cond, uint8_t* __restrict__ tex,
                                                uint32_t st_first, uint32_t st_end, uint32_t step, uint8_t* lds)
 {
-    // (the table -- written by the prepare kernel, constant here -- is read through the constant address space: every word a scalar load.  As
+    // (the table -- written by the schedule kernel, constant here -- is read through the constant address space: every word a scalar load.  As
     // plain global memory, even behind __restrict__, its words came as one vector load per lane each, waited for in front of the loads they
     // are the addresses of, and kept in vector registers)
     const BROTLIG_CONSTANT_AS DcTable& t = *(const BROTLIG_CONSTANT_AS DcTable*)tp;
@@ -292,7 +292,7 @@ __device__ __forceinline__ uint32_t dc_texture(const DcTable* __restrict__ tp, c
 __device__ __forceinline__ void dc_walk(const DecodeArgs& a, uint32_t first, uint32_t end, uint32_t step, uint8_t* lds)
 {
     if (first >= end) return;
-    // (the tables were written by the prepare kernels and are constant here: wave-uniform words through the constant address space are
+    // (the tables were written by the schedule kernel and are constant here: wave-uniform words through the constant address space are
     // scalar loads)
     const BROTLIG_CONSTANT_AS DcTable* const dc = (const BROTLIG_CONSTANT_AS DcTable*)a.dc;
     // the stream `first` falls into: the last one whose super-tiles begin at or before it (streams without any share their successor's base and sort before it)

@@ -222,7 +222,7 @@ BROTLIG_ERROR enqueue(const DecodeArgs& args, hipStream_t s, hipEvent_t k0, hipE
         // Which kernel: up to kDuoMaxPages pages two wavefronts per page (brotlig_decode_duo_kernel), more than that one wavefront per
         // one or two pages.  The host knows the output size, not the page count (32 .. 128 KiB each): where the size leaves both
         // possible (up to 256 MiB of output) both kernels are launched and the one the batch does not belong to leaves at once
-        // (DecodeArgs::duo_limit against the page count the prepare kernel found) -- a few microseconds, and only for such batches.
+        // (DecodeArgs::duo_limit against the page count the schedule kernel found) -- a few microseconds, and only for such batches.
         const uint64_t bound = max_pages(a.num_streams, a.out_bytes);
         const uint32_t mode = g_debug_mode.load(), forced = g_debug_grid.load();
         DecodeArgs b = a;
@@ -239,7 +239,7 @@ BROTLIG_ERROR enqueue(const DecodeArgs& args, hipStream_t s, hipEvent_t k0, hipE
         }
     }
     if (k1) HIP_OK(hipEventRecord(k1, s));
-    if (a.scratch != nullptr) {   // (without a scratch buffer no stream of the batch can be pre-conditioned: the prepare kernel rejects them)
+    if (a.scratch != nullptr) {   // (without a scratch buffer no stream of the batch can be pre-conditioned: the schedule kernel rejects them)
         // The batch's super-tiles (2 x 128 blocks: 2 or 4 KiB of texture) are one list, cut evenly over the wavefronts of this launch, 32 per CU
         // at most; a small batch does not need them all (the count is an estimate -- the kernel divides whatever list it finds by the grid).
         const uint64_t want = a.out_bytes / 4096u + a.num_streams;

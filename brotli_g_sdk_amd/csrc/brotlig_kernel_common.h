@@ -26,7 +26,7 @@ __device__ __forceinline__ uint64_t stream_out_end(const StreamDesc& d, uint64_t
     return (d.out_capacity != 0u && e < out_bytes) ? e : out_bytes;
 }
 
-// Per-stream pre-conditioning parameters, derived once per launch by the prepare kernel from the
+// Per-stream pre-conditioning parameters, derived once per launch by the schedule kernel (its prepare phase) from the
 // 8-byte PreconditionHeader (inc/DataStream.h:89-98) the way
 // BrotligDataconditionParams::Initialize does (inc/common/BrotligDataConditioner.h:92-237).
 struct DcTable {

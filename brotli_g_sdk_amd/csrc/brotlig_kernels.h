@@ -22,7 +22,7 @@
 //   * the distance ring travels from round to round through LDS (the last four pushes of a round, written by
 //     their lanes) instead of being rebuilt from lane broadcasts;
 //   * work is pulled from one device-side counter by persistent waves, through a page schedule
-//     that puts similar pages side by side (order kernels below).
+//     that puts similar pages side by side (brotlig_schedule.h).
 //
 // Style rule: every wave::* call sits in wave-uniform control flow.  Per-lane loops and
 // branches contain only memory and ALU work.  (tests/sim runs this same source on the CPU with

@@ -279,7 +279,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
     const TableRef t_dist{L.lut_dist, L.sorted_dist, L.limit[1], L.first_offs[1], kDistAlphabet, kLutBitsDist, far_syms};
     const TableRef t_lit{L.lut_lit, L.sorted_lit, L.limit[2], L.first_offs[2], kLitAlphabet, kLutBitsLit, nullptr};
 
-    const uint32_t resync_quarters = a.status[3];                       // pairing policy, set by the prepare kernel
+    const uint32_t resync_quarters = a.status[3];                       // pairing policy, set by the schedule kernel
     // ---- per-half state of the page under construction
     PageJob job = no_job(a);
     bool live = false;               // inside a compressed page
@@ -305,7 +305,7 @@ __device__ inline void decode_pages(WaveLds& W, const DecodeArgs& a, unsigned lo
     for (;;) {
         // ---- page start.  A half without a page takes one -- unless the other half is within
         //      resync_quarters / 4 of finishing its own page: then it waits and both start together (one
-        //      joint table build instead of two single ones).  The prepare kernel sets the threshold per
+        //      joint table build instead of two single ones).  The schedule kernel sets the threshold per
         //      launch: 1 when neighbouring pages differ in cost (a free half starts over at once), 4 when
         //      they are alike -- then the halves stay in step, which keeps rounds of the same shape
         //      paired (measured on the BC3 config: 7 % faster in step than out of phase).

@@ -112,7 +112,7 @@ extern "C" int sim_decode_batch(const uint8_t* in, uint64_t in_bytes, uint8_t* o
 }
 
 
-extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word 3: pairing policy chosen by the prepare kernel
+extern "C" uint32_t sim_last_policy() { return g_last_policy; }   // status word 3: pairing policy chosen by the schedule kernel
 extern "C" void sim_set_order(int on) { g_use_order = on; }
 extern "C" void sim_set_order_from_k(uint32_t k) { g_order_from_k = (uint16_t)k; }
 extern "C" void sim_selftest(uint32_t* out) { sim::run_grid(1, selftest_body, out); }

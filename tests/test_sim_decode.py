@@ -159,7 +159,7 @@ def test_sim_wave_primitives(sim):
 
 
 def test_sim_pairing_policy(sim):
-    """The prepare kernel compares the compressed sizes of neighbouring pages: a stream that mixes page
+    """The schedule kernel compares the compressed sizes of neighbouring pages: a stream that mixes page
     kinds page by page lets the halves of a wavefront run free (threshold 1 quarter), a homogeneous one
     keeps them in step (4 quarters).  Either way the output is the same."""
     from brotli_g_sdk_amd import datagen as D
@@ -179,7 +179,7 @@ def test_sim_pairing_policy(sim):
 
 
 def test_sim_page_schedule_on_and_off(sim):
-    """The page schedule (order kernels: pages grouped into size buckets, dense first) only changes which
+    """The page schedule (the schedule kernel's count and scatter phases: pages grouped into size buckets, dense first) only changes which
     half-wave decodes which page; the output is identical with and without it, for plain and
     pre-conditioned streams in one batch."""
     from brotli_g_sdk_amd import datagen as D
@@ -414,7 +414,7 @@ def test_sim_decondition_large_textures_go_to_gangs_of_256(sim, grid):
 
 @pytest.mark.parametrize("grid,what", [(2, "page order"), (4, "folded"), (6, "folded"), (7, "one page per wavefront")])
 def test_sim_schedule_modes_of_a_small_batch(sim, grid, what):
-    """What the order kernels write for a batch below the schedule's own threshold (the host: 12 288 pages; here raised above the batch
+    """What the schedule kernel writes for a batch below the schedule's own threshold (the host: 12 288 pages; here raised above the batch
     through sim_set_order_from_k): page order -- unless the batch has more pages than the page kernel has wavefronts and at most twice as
     many, then the schedule FOLDED, front and back in turn, so that the two halves of a wavefront get the densest and the lightest page
     (schedule_mode in brotlig_kernels.h, late round 5).  Seven pages of very different cost (text, runs, stored, a short last page) on 2, 4,
@@ -433,7 +433,7 @@ def test_sim_schedule_modes_of_a_small_batch(sim, grid, what):
 
 def test_sim_host_rule_exactly_one_kernel_decodes(sim):
     """The host launches BOTH page kernels when the output size leaves the page count open, and the device decides (DecodeArgs::duo_limit
-    against the page count the prepare kernel found); it skips the policy kernel when no two pages can meet (csrc/brotlig_hip.hip enqueue()).
+    against the page count the prepare kernel found); it leaves the pairing policy at 0 when no two pages can meet (csrc/brotlig_hip.hip enqueue()).
     The same sequence on the simulator, with a small injected limit: page counts on both sides of it -- and AT it -- are decoded
     by exactly one of the two kernels (the page counter moves under one of them only), bit-exact either way."""
     for name in ("sim_counter_after_duo", "sim_counter_after_classic"):
