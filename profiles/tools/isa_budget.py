@@ -139,7 +139,7 @@ def stage_table(src_lines):
 def stage_of(stack, marks, fn_line):
     # the frame of decode_pages<>: its line says where in the round the instruction belongs
     for fn, f, line in stack:
-        if fn.startswith("decode_pages") and f == "brotlig_kernels.h":
+        if fn.startswith("decode_pages") and f == "brotlig_round.h":
             if line < marks[0][1]:
                 return "0 wave setup"
             for k in range(len(marks) - 1):
@@ -207,7 +207,7 @@ def main():
     same = size == size_n
     stacks = symbolize(co_g, [i["addr"] for i in insts])
     assert len(stacks) == len(insts), (len(stacks), len(insts))
-    src = open(os.path.join(CSRC, "brotlig_kernels.h")).read().split("\n")
+    src = open(os.path.join(CSRC, "brotlig_round.h")).read().split("\n")     # (decode_pages<> lives there since the header was split per stage)
     fn_line, marks = stage_table(src)
 
     # control flow: back edges -> natural loops as address intervals [target, branch]

@@ -6,7 +6,7 @@ their damaged twins, 20 random pre-conditioned streams and theirs.  Build and ru
   LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python profiles/tools/sim_sanitize.py"""
 import ctypes, sys, numpy as np
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
-import test_sim_decode as T, test_sim_split as S
+import test_sim_decode as T
 from brotli_g_sdk_amd import encoder as E, datagen as D
 from cases import plain_cases, raw_stress_cases, precon_cases, symbol_overflow_cases
 from fuzzcases import random_plain, random_precon, corrupt
