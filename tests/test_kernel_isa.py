@@ -66,3 +66,14 @@ def test_the_float_reciprocal_division_is_inexact_for_24_bit_operands():
     a, b = np.float32(13258079), np.float32(11)
     q = np.trunc(a * (np.float32(1) / b))
     assert int(q) == 13258079 // 11 + 1
+
+
+def test_stage_budget_tool_finds_its_markers_in_the_split_headers():
+    """profiles/tools/isa_budget.py books every instruction of the page loop to a stage of a round by marker comments in the source of
+    decode_pages<> -- which moved from brotlig_kernels.h to brotlig_round.h when the header was split per stage (round 6), and the tool stopped
+    working unnoticed.  No compiler needed: the markers must all be there, in order."""
+    import isa_budget
+    src = open(os.path.join(isa_budget.CSRC, "brotlig_round.h")).read().split("\n")
+    fn_line, marks = isa_budget.stage_table(src)
+    lines = [ln for _, ln in marks]
+    assert fn_line < lines[0] and lines == sorted(lines) and len(set(lines)) == len(lines), marks
