@@ -57,13 +57,21 @@ def kernel_headers():
     return sorted(h for h in glob.glob(os.path.join(CSRC, "brotlig_*.h")) if not h.endswith(skip))
 
 
+# How the device code is compiled, in ONE place (profiles/tools/isa_budget.py, tests/test_bench_gating.py and the shell tools under
+# profiles/tools build variants of the kernels with the same flags).  -fno-unroll-loops since round 6: the loop unroller's own choices cost
+# the page kernel forty spilled values and a fifth of its code (13 527 -> 10 780 instructions); without them every data class decodes
+# 1.0 .. 2.1 % faster, and the round loop has room for the runs-first team levels (profiles/experiments/README.md).  Loops that index
+# small register arrays carry `#pragma unroll` (the per-page delta decode), which the flag leaves alone.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-unroll-loops"]
+
+
 def build_hip(force=False):
     override = os.environ.get("BROTLIG_HIP_SO")     # diagnostics: load an alternative build of the library
     if override:
         return override
     src = hip_sources()
     if force or _stale(HIP_SO, src):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        cmd = [_hipcc()] + HIP_FLAGS + ["-fPIC", "-shared",
                "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-o", HIP_SO, src[0], src[1]]
         subprocess.check_call(cmd, cwd=CSRC)
     return HIP_SO

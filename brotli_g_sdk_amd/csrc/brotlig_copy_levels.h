@@ -89,6 +89,17 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
 #ifndef BROTLIG_TUNE_PLAIN_LEVELS
 #define BROTLIG_TUNE_PLAIN_LEVELS 1
 #endif
+// Runs first (round 6): in a team level that holds runs (pieces that repeat a period of 1, 2, 4 or 8 bytes) AND other pieces, the runs are
+// served first, by teams of their own and with the cheap loop (one pattern word per piece, read by its owner; no remainder and no pattern
+// read per chunk); the general loop then serves the rest with more lanes per piece.  Until then a level was ONE pass over all ready pieces
+// and took the cheap loop only when every served piece of BOTH halves was a run -- a quarter of the team levels of run-length pages, whose
+// levels hold 2.1 runs and 0.7 other pieces on average (profiles/tools/cmd_stats.c).  Run-length pages +16 %, config 2 +7.5 %.  In the
+// kernel as it was compiled until round 6 the code cost every other class 1 .. 2.5 % by its presence (register allocation of the round
+// loop); built without the loop unroller's choices (-fno-unroll-loops, _build.HIP_FLAGS: forty spilled values fewer) it costs none.
+// 0: the single pass.
+#ifndef BROTLIG_TUNE_RUNS_FIRST
+#define BROTLIG_TUNE_RUNS_FIRST 1
+#endif
 // The same for a group in which every piece that takes part is simple and at most 32 bytes long (decided once per group by the
 // caller, for both halves): a level is then one batch of own-lane chunk copies and nothing else -- no question about teams, about
 // further batches or about the overlap path in any iteration.  (Round 4: those three questions are ~19 of a level's ~90 issued
@@ -252,21 +263,55 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
             }
         } else {
         clk.count(kPhTeamLevels, 1);
+        uint32_t serve_mask = ready_mask;       // the pieces (lanes of the half) that the teams below serve
+#if BROTLIG_TUNE_RUNS_FIRST
+        {
+            // runs: the piece overlaps itself with a period of 1, 2, 4 or 8 bytes and its pattern lies in one place (a piece that lies in one
+            // place and is not simple has a distance below 32 and below its length).  Asked here and not once per group: a group's masks live
+            // in scalar registers across the level loop, and the loop has none to spare.
+            const uint64_t runs_w = ready_w & whole_w & ~simple_w & ((wave::ballot_lt_k<5u>(dist) & ~wave::ballot_eq_k<3u>(dist)) | wave::ballot_eq_k<8u>(dist));
+            if (runs_w != 0ull && runs_w != ready_w) {
+                const bool run = wave::from_mask(runs_w);
+                uint64_t word = 0;                                  // the owner reads its pattern; the team members get the word
+                if (run) word = pattern_source8(far_len ? reinterpret_cast<const uint8_t*>(stage) + stage_off : win + (int32_t)src_idx, dist, 0u);
+                uint32_t r_mask = wave::half_of(runs_w);
+                Team rt;
+                uint32_t r_lo, r_hi, r_len, r_dst;
+                if (solo) {
+                    r_mask = wave::bcast(r_mask, 0u);
+                    rt = make_team64(r_mask, wave::lane_id());
+                    r_lo = wave::bcast((uint32_t)word, rt.job); r_hi = wave::bcast((uint32_t)(word >> 32), rt.job);
+                    r_len = wave::bcast(plen, rt.job); r_dst = wave::bcast(dst_idx, rt.job);
+                } else {
+                    rt = make_team(r_mask, sl);
+                    r_lo = wave::half_shfl((uint32_t)word, rt.job); r_hi = wave::half_shfl((uint32_t)(word >> 32), rt.job);
+                    r_len = wave::half_shfl(plen, rt.job); r_dst = wave::half_shfl(dst_idx, rt.job);
+                }
+                const bool r_act = rt.serves && r_mask != 0u;
+                const uint64_t v = (uint64_t)r_lo | ((uint64_t)r_hi << 32);
+                for (uint32_t c = rt.member; wave::any(r_act && 8u * c < r_len); c += 1u << rt.log2_size) {
+                    const uint32_t j = 8u * c;
+                    if (r_act && j < r_len) store_bytes(win + r_dst + j, v, r_len - j);
+                }
+                serve_mask = ready_mask & ~wave::half_of(runs_w);
+            }
+        }
+#endif
         // Small batches (round 4): a wavefront that decodes one page lends the idle upper half to the teams -- twice the lanes
         // per long piece.  All 64 lanes work in the one record of the wavefront (PageRecord<true>); the upper lanes take the
         // pieces' fields from the lower half's lanes.
         Team t;
-        uint32_t t_pk, t_dist, t_src, t_dst, team_mask = ready_mask;
+        uint32_t t_pk, t_dist, t_src, t_dst, team_mask = serve_mask;
         uint8_t* t_lds = win;
         const uint8_t* t_stg = reinterpret_cast<const uint8_t*>(stage);
         if (solo) {
             const uint32_t lane = wave::lane_id();
-            team_mask = wave::bcast(ready_mask, 0u);
+            team_mask = wave::bcast(serve_mask, 0u);
             t = make_team64(team_mask, lane);
             t_pk = wave::bcast(packed, t.job); t_dist = wave::bcast(dist, t.job);
             t_src = wave::bcast(src_idx, t.job); t_dst = wave::bcast(dst_idx, t.job);
         } else {
-            t = make_team(ready_mask, sl);
+            t = make_team(serve_mask, sl);
             t_pk = wave::half_shfl(packed, t.job); t_dist = wave::half_shfl(dist, t.job);
             t_src = wave::half_shfl(src_idx, t.job); t_dst = wave::half_shfl(dst_idx, t.job);
         }
@@ -347,6 +392,7 @@ __device__ __forceinline__ void delta_decode_page(const PageJob& job, bool do_de
             if (full) {
                 __builtin_memcpy(w, __builtin_assume_aligned(job.out + pos, 16), 16);
             } else {
+#pragma unroll
                 for (uint32_t i = 0; i < 16u; ++i)
                     if (pos + i >= lo && pos + i < hi) w[i >> 2] |= (uint32_t)job.out[pos + i] << (8u * (i & 3u));
             }
@@ -357,10 +403,12 @@ __device__ __forceinline__ void delta_decode_page(const PageJob& job, bool do_de
             const uint32_t total = w[3] >> 24;
             const uint32_t incl = wave::half_scan_incl(total) & 0xFFu;
             const uint32_t add = (carry + incl - total) & 0xFFu;
+#pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) w[k] = byte_add(w[k], add);
             if (full) {
                 __builtin_memcpy(__builtin_assume_aligned(job.out + pos, 16), w, 16);
             } else {
+#pragma unroll
                 for (uint32_t i = 0; i < 16u; ++i)
                     if (pos + i >= lo && pos + i < hi) job.out[pos + i] = (uint8_t)(w[i >> 2] >> (8u * (i & 3u)));
             }

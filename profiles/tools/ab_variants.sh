@@ -6,7 +6,7 @@ if [ "$1" = build ]; then
   shift; rm -rf build/abv; mkdir -p build/abv
   for v in "base:" "$@"; do
     name=${v%%:*}; flags=${v#*:}
-    ( cd brotli_g_sdk_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared $flags -I ../../include -I . \
+    ( cd brotli_g_sdk_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-unroll-loops -fPIC -shared $flags -I ../../include -I . \
         -o ../../build/abv/lib_$name.so brotlig_hip.hip brotlig_streamer.hip 2>&1 | grep -i " error" ) &
   done
   wait; ls build/abv

@@ -7,7 +7,7 @@ masks="0 1 2 4 8 32 64 128 239"
 if [ "$1" = build ]; then
   mkdir -p build/ablate
   for m in $masks; do
-    ( cd brotli_g_sdk_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DBROTLIG_ABLATE=$m -I ../../include -I . \
+    ( cd brotli_g_sdk_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-unroll-loops -fPIC -shared -DBROTLIG_ABLATE=$m -I ../../include -I . \
         -o ../../build/ablate/libbrotlig_hip_$m.so brotlig_hip.hip brotlig_streamer.hip ) &
   done
   wait; ls -la build/ablate/*.so

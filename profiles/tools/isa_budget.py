@@ -38,7 +38,9 @@ def build(flags, debug):
     tag = "g" if debug else "n"
     obj = os.path.join(OUT, f"budget_{tag}.o")
     co = os.path.join(OUT, f"budget_{tag}.co")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    sys.path.insert(0, ROOT)
+    from brotli_g_sdk_amd._build import HIP_FLAGS                      # the product's flags
+    cmd = ["hipcc"] + HIP_FLAGS + ["--cuda-device-only", "-c", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     if debug:
         cmd.append("-g")
     cmd += flags + [os.path.join(CSRC, "brotlig_hip.hip"), "-o", obj]

@@ -16,7 +16,8 @@ CSRC = os.path.join(ROOT, "brotli_g_sdk_amd", "csrc")
 
 
 def _variant(path, flags):
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
+    from brotli_g_sdk_amd._build import HIP_FLAGS
+    subprocess.check_call(["hipcc"] + HIP_FLAGS + ["-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
                            "-I", CSRC, "-o", path, os.path.join(CSRC, "brotlig_hip.hip")] + flags, cwd=CSRC,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return path
