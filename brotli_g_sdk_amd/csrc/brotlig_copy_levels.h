@@ -97,6 +97,9 @@ __device__ __forceinline__ void flush_and_slide(OutView& view, uint32_t& flushed
 // kernel as it was compiled until round 6 the code cost every other class 1 .. 2.5 % by its presence (register allocation of the round
 // loop); built without the loop unroller's choices (-fno-unroll-loops, _build.HIP_FLAGS: forty spilled values fewer) it costs none.
 // 0: the single pass.
+#ifndef BROTLIG_TUNE_DELTA_UNROLL
+#define BROTLIG_TUNE_DELTA_UNROLL 1
+#endif
 #ifndef BROTLIG_TUNE_RUNS_FIRST
 #define BROTLIG_TUNE_RUNS_FIRST 1
 #endif
@@ -377,6 +380,9 @@ __device__ __forceinline__ void delta_decode_page(const PageJob& job, bool do_de
 {
     if (!wave::any(do_delta)) return;
     wave::global_fence();                       // the page's own stores first
+#if BROTLIG_TUNE_DELTA_UNROLL
+#pragma unroll
+#endif
     for (uint32_t c = 0; c < kMaxSubBlocks; ++c) {
         uint32_t lo = 0, hi = 0;
         if (do_delta && ((job.dc->color_mask >> c) & 1u)) {

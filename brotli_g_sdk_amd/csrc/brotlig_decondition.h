@@ -35,6 +35,7 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
     t.precon = 1; t.swizzle = w0 & 1u; t.block_bytes = bb; t.num_sub = nsub; t.color_mask = color;
     t.num_mips = ((w1 >> 8) & 0x1Fu) + 1u;
     uint32_t off = 0;
+#pragma unroll
     for (uint32_t i = 0; i < kMaxSubBlocks; ++i) {
         t.sub_size[i] = i < nsub ? (sizes >> (4u * i)) & 15u : 0u;
         t.sub_off[i] = off; off += t.sub_size[i];
@@ -70,6 +71,7 @@ __device__ inline bool dc_init(DcTable& t, uint32_t w0, uint32_t w1, uint32_t ou
     if (!fits) return false;
     t.total_blocks = (uint32_t)total; t.tex_bytes = (uint32_t)(total * bb);
     t.sub_stream_off[0] = 0;
+#pragma unroll
     for (uint32_t i = 0; i < kMaxSubBlocks; ++i) t.sub_stream_off[i + 1] = t.sub_stream_off[i] + t.total_blocks * t.sub_size[i];
     return bytes == (uint64_t)out_size;                                 // :219
 }
