@@ -57,7 +57,35 @@ def plain_cases():
         ("short_periodic_runs", short_periodic_runs, {}),
         ("short_periodic_runs_greedy", short_periodic_runs, dict(flags=E.NO_LAZY)),
         ("periodic_runs_to_40", lambda: short_periodic_runs(41), {}),       # with pieces above 32 bytes among them: those levels run in teams
+        # long runs of every period next to long copies of earlier bytes, a literal or two between them: team levels that hold runs (periods 1, 2,
+        # 4, 8: served first, by teams of their own -- round 6) AND other long pieces (periods 3, 5, 6, 7, 12, 20; plain copies from near and far)
+        ("long_runs_beside_long_copies", long_runs_beside_long_copies, {}),
+        ("long_runs_beside_long_copies_greedy", long_runs_beside_long_copies, dict(flags=E.NO_LAZY)),
     ]
+
+
+def long_runs_beside_long_copies():
+    rng = np.random.default_rng(606)
+    base = rng.integers(0, 256, 3000, dtype=np.uint8)
+    parts = [base]
+    total = len(base)
+    while total < 3 * 65536 + 1234:
+        kind = int(rng.integers(0, 3))
+        if kind < 2:                                                    # a run
+            period = int(rng.choice([1, 2, 4, 8, 1, 2, 3, 5, 6, 7, 12, 20]))
+            length = int(rng.integers(34, 420))
+            pat = rng.integers(0, 256, period, dtype=np.uint8)
+            piece = np.tile(pat, length // period + 2)[:period + length]
+        else:                                                           # a copy of something earlier: near (inside the window) or far
+            length = int(rng.integers(34, 320))
+            whole = np.concatenate(parts) if len(parts) > 1 else parts[0]
+            parts = [whole]
+            back = int(rng.integers(length, min(len(whole), 600 if rng.random() < 0.7 else 40000)))
+            piece = whole[len(whole) - back:len(whole) - back + length].copy()
+        sep = rng.integers(0, 256, int(rng.integers(0, 3)), dtype=np.uint8)
+        parts += [sep, piece]
+        total += len(sep) + len(piece)
+    return np.concatenate(parts)
 
 
 def short_periodic_runs(length_end=33):
