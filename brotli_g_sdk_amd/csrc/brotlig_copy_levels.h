@@ -151,13 +151,18 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
     const uint64_t whole_w = wave::ballot_eq0(far_len) | wave::ballot_eq(far_len, pattern);         // pattern in one place
     const uint64_t simple_w = whole_w & (wave::ballot_gt_k<31u>(dist) | ~wave::ballot_lt(dist, plen));
     const bool simple = wave::from_mask(simple_w);
-    const uint64_t long_w = (simple_w & wave::ballot_gt_k<kOwnCopy>(plen)) | (~simple_w & wave::ballot_gt_k<kShortCopy>(plen));
     const uint64_t ge8_w = wave::ballot_gt_k<7u>(plen), gt32_w = wave::ballot_gt_k<32u>(plen);
 #if BROTLIG_TUNE_POW2_OVERLAP
     // self-overlapping pieces with a period of 1, 2 or 4 bytes whose pattern lies in one place (asked once per group, and only when there is a
     // piece that overlaps itself at all)
     const uint64_t pow2_dist_w = (~simple_w & todo_w) != 0ull ? whole_w & ~simple_w & wave::ballot_lt_k<5u>(dist) & ~wave::ballot_eq_k<3u>(dist) : 0ull;
+#else
+    const uint64_t pow2_dist_w = 0ull;
 #endif
+    // long pieces make their level a team level: simple ones beyond kOwnCopy bytes, others beyond kShortCopy -- except the periods of 1, 2 and 4
+    // bytes, which are one word stored kOverlapOwn / 8 times at most by their own lane (round 6: 48 instead of 32 -- 16-bit samples +3.7 %)
+    const uint64_t long_w = (simple_w & wave::ballot_gt_k<kOwnCopy>(plen)) | (~simple_w & ~pow2_dist_w & wave::ballot_gt_k<kShortCopy>(plen)) |
+                            (pow2_dist_w & wave::ballot_gt_k<kOverlapOwn>(plen));
     while (todo_w != 0ull) {
         clk.count(kPhLevels, 1);
         clk.halves(kPhLevelHalves, todo != 0u);
@@ -220,6 +225,13 @@ __device__ __forceinline__ void copy_levels(uint8_t* win, const uint64_t* stage,
                             if (n > 8u) __builtin_memcpy(q + c8, &vt, 8);
                             if (n >= 16u) __builtin_memcpy(q + 8u, &v, 8);
                             if (n >= 24u) __builtin_memcpy(q + 16u, &v, 8);
+                            if constexpr (kOverlapOwn > 32u) {          // (whole words from 24 on: the last one is the rotated word at n - 8)
+                                if (n > 32u) {
+#pragma unroll
+                                    for (uint32_t o = 24u; o + 8u < kOverlapOwn; o += 8u)
+                                        if (n > o + 8u) __builtin_memcpy(q + o, &v, 8);
+                                }
+                            }
                         } else store_bytes(q, v, n);
                     }
                     rest_w &= ~pow2_w;

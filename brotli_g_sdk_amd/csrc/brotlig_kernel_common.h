@@ -197,6 +197,14 @@ constexpr uint32_t kFarSymStride = (kFarIcp + kFarDist + 63u) & ~63u;   // uint1
 constexpr uint32_t kLongCode = 0xFFFFu;     // LUT marker: code longer than the LUT index, lengths differ under the prefix
 constexpr uint32_t kLutSubtree = 0x8000u;   // LUT flag: longer code, one length under the prefix: {index in code order, length}
 constexpr uint32_t kShortCopy = BROTLIG_TUNE_SHORT_COPY;         // far pieces up to this length are fetched by their own lane (four 8-byte loads)
+// Pieces that are not simple (they overlap themselves with a distance below 32, or their pattern straddles the window boundary) run in their
+// own lane up to kShortCopy bytes, a longer one makes its level a team level -- except the pieces with a period of 1, 2 or 4 bytes (one word,
+// stored by its lane: no read back): those stay with their lane up to kOverlapOwn bytes.
+#ifndef BROTLIG_TUNE_OVERLAP_OWN
+#define BROTLIG_TUNE_OVERLAP_OWN 48
+#endif
+constexpr uint32_t kOverlapOwn = BROTLIG_TUNE_OVERLAP_OWN;
+static_assert(kOverlapOwn >= 32u && kOverlapOwn <= 64u && kOverlapOwn % 8u == 0u, "the period-1/2/4 path stores up to kOverlapOwn / 8 words");
 constexpr uint32_t kOwnCopy = BROTLIG_TUNE_OWN_COPY;             // simple copies up to this length run one-lane-per-command (batches of four 8-byte chunks)
 // Output window: the last kWin bytes of the page under construction live in LDS.  A round whose
 // output fits in kWin - kHist bytes is assembled there (literals, copies, the dependency levels
