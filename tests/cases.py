@@ -57,6 +57,9 @@ def plain_cases():
         ("short_periodic_runs", short_periodic_runs, {}),
         ("short_periodic_runs_greedy", short_periodic_runs, dict(flags=E.NO_LAZY)),
         ("periodic_runs_to_40", lambda: short_periodic_runs(41), {}),       # with pieces above 32 bytes among them: those levels run in teams
+        # ... and up to 56: the periods 1, 2 and 4 stay with their lane up to 48 bytes (kOverlapOwn, round 6: one word stored up to six times),
+        # every other period and every longer run makes its level a team level
+        ("periodic_runs_to_56", lambda: short_periodic_runs(57), {}),
         # long runs of every period next to long copies of earlier bytes, a literal or two between them: team levels that hold runs (periods 1, 2,
         # 4, 8: served first, by teams of their own -- round 6) AND other long pieces (periods 3, 5, 6, 7, 12, 20; plain copies from near and far)
         ("long_runs_beside_long_copies", long_runs_beside_long_copies, {}),
